@@ -1,0 +1,338 @@
+// oracle/model.cpp — TEST INFRASTRUCTURE ONLY (see oracle.h).
+//
+// CPU restatement of the reference's decode graph for Llama-family models (dense SwiGLU FFN or
+// Mixtral-style MoE), in the reference's op order:
+//
+//   LlamaModel::forward / compute_logits         src/model/llama.rs:247-362
+//   TransformerLayer::forward (serial residual)  src/model/layers.rs:1082-1245
+//   Attention::forward (full-attention branch)   src/model/layers.rs:409-704
+//   FeedForward::forward                         src/model/layers.rs:908-929
+//   MoeLayer / MoeExpert::forward                src/model/moe.rs:227-268, 321-413
+//   Linear::forward (+bias)                      src/model/layers.rs:56-77
+//   KVCache layout [kv_heads, max_seq, head_dim] src/model/mod.rs:64-108
+//   tensor names                                 src/model/loader.rs:592-854, 1140-1313
+#include "oracle.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+void orc_parallel_for(size_t total, size_t grain, const std::function<void(size_t, size_t)>& fn);
+
+namespace {
+
+struct TensorRef {
+  int type = -1;
+  uint64_t ne[4] = {0, 0, 0, 0};
+  const uint8_t* data = nullptr;
+  size_t nbytes = 0;
+  std::vector<uint8_t> owned;
+  bool present() const { return data != nullptr; }
+  size_t numel() const { return (size_t)(ne[0] * (ne[1] ? ne[1] : 1) * (ne[2] ? ne[2] : 1) * (ne[3] ? ne[3] : 1)); }
+};
+
+struct LinearRef {  // GGUF: weight [in_features, out_features]
+  const TensorRef* w = nullptr;
+  const TensorRef* bias = nullptr;
+  size_t in_f = 0, out_f = 0;
+};
+
+struct ExpertRef {
+  const uint8_t *gate = nullptr, *up = nullptr, *down = nullptr;
+  int gate_type = 0, up_type = 0, down_type = 0;
+};
+
+struct LayerRef {
+  const TensorRef *attn_norm = nullptr, *ffn_norm = nullptr;
+  LinearRef wq, wk, wv, wo, gate, up, down;
+  const TensorRef* router = nullptr;  // ffn_gate_inp.weight [hidden, n_experts] f32
+  std::vector<ExpertRef> experts;
+};
+
+}  // namespace
+
+struct orc_model {
+  orc_config cfg;
+  std::map<std::string, TensorRef> tensors;
+  std::vector<LayerRef> layers;
+  const TensorRef* token_embd = nullptr;
+  const TensorRef* output_norm = nullptr;
+  LinearRef output;
+  std::vector<float> embd_f32;  // dequantized table (kept unless faithful mode re-does it per call)
+  std::vector<std::vector<float>> k_cache, v_cache;  // per layer [kv_heads][max_seq][head_dim]
+  std::vector<float> last_hidden;
+  size_t position = 0;
+  bool finalized = false;
+  std::string err;
+};
+
+namespace {
+
+int fail(orc_model* m, const std::string& s) {
+  m->err = s;
+  return 1;
+}
+
+// Linear::forward (layers.rs:56-77): quantized -> vec_mat_q, else vec_mat (F32 only); then += bias
+int linear_forward(orc_model* m, const LinearRef& l, const float* x, float* out) {
+  if (!l.w) return fail(m, "missing linear weight");
+  if (l.w->type == ORC_F32) {
+    orc_vec_mat_f32((const float*)l.w->data, x, out, l.in_f, l.out_f);
+  } else if (l.w->type == ORC_F16 || l.w->type == ORC_BF16) {
+    // quirk Q3: the CPU path rejects non-F32 dense weights (ops.rs:960-962)
+    return fail(m, "F16/BF16 2-D weights are rejected by the reference CPU path (ops.rs:960)");
+  } else if (orc_vec_mat_q(l.w->type, l.w->data, x, out, l.in_f, l.out_f)) {
+    return fail(m, "vec_mat_q failed");
+  }
+  if (l.bias) {
+    const float* b = (const float*)l.bias->data;
+    for (size_t i = 0; i < l.out_f; i++) out[i] += b[i];
+  }
+  return 0;
+}
+
+int raw_vec_mat(orc_model* m, int type, const uint8_t* w, const float* x, float* out, size_t k, size_t n) {
+  if (type == ORC_F32) {
+    orc_vec_mat_f32((const float*)w, x, out, k, n);
+    return 0;
+  }
+  if (orc_vec_mat_q(type, w, x, out, k, n)) return fail(m, "expert vec_mat_q failed");
+  return 0;
+}
+
+const TensorRef* find(orc_model* m, const std::string& name) {
+  auto it = m->tensors.find(name);
+  return it == m->tensors.end() ? nullptr : &it->second;
+}
+
+int bind_linear(orc_model* m, LinearRef& l, const std::string& base, bool required) {
+  l.w = find(m, base + ".weight");
+  if (!l.w) return required ? fail(m, "missing tensor " + base + ".weight") : 0;
+  l.bias = find(m, base + ".bias");
+  l.in_f = (size_t)l.w->ne[0];
+  l.out_f = (size_t)l.w->ne[1];
+  return 0;
+}
+
+// Attention::forward, full-attention / standard-RoPE branch (layers.rs:409-704)
+int attention_forward(orc_model* m, size_t li, const float* x, size_t pos, float* out) {
+  const orc_config& c = m->cfg;
+  const LayerRef& L = m->layers[li];
+  size_t nh = c.num_heads, nkv = c.num_kv_heads, d = c.head_dim;
+  std::vector<float> q(nh * d), k(nkv * d), v(nkv * d);
+  if (linear_forward(m, L.wq, x, q.data())) return 1;  // 438
+  if (linear_forward(m, L.wk, x, k.data())) return 1;  // 439
+  if (linear_forward(m, L.wv, x, v.data())) return 1;  // 440
+  orc_rope(q.data(), k.data(), nh, nkv, 1, d, pos, c.rope_freq_base, c.rope_freq_scale, (int)c.use_neox_rope);  // 565-575
+  float* kc = m->k_cache[li].data();
+  float* vc = m->v_cache[li].data();
+  size_t ms = c.max_seq_len;
+  for (size_t h = 0; h < nkv; h++) {  // 577-600
+    std::memcpy(kc + h * ms * d + pos * d, k.data() + h * d, d * 4);
+    std::memcpy(vc + h * ms * d + pos * d, v.data() + h * d, d * 4);
+  }
+  std::vector<float> attn(nh * d);
+  float scale = 1.0f / std::sqrt((float)d);  // layers.rs:374
+  orc_attention_cached(q.data(), kc, vc, attn.data(), nh, nkv, d, ms, scale, pos + 1);  // 675-682
+  return linear_forward(m, L.wo, attn.data(), out);  // 700-701
+}
+
+// FeedForward::forward (layers.rs:908-929)
+int dense_ffn_forward(orc_model* m, const LayerRef& L, const float* x, float* out) {
+  size_t ffn = L.gate.out_f;
+  std::vector<float> g(ffn), u(ffn);
+  if (linear_forward(m, L.gate, x, g.data())) return 1;
+  if (linear_forward(m, L.up, x, u.data())) return 1;
+  orc_silu_mul_inplace(g.data(), u.data(), ffn);
+  return linear_forward(m, L.down, g.data(), out);
+}
+
+// MoeLayer::forward (moe.rs:321-413) with MoeExpert::forward (227-268); router normalize=false (loader.rs:1155-1159)
+int moe_forward(orc_model* m, const LayerRef& L, const float* x, float* out) {
+  const orc_config& c = m->cfg;
+  size_t hidden = c.hidden_size, ne = c.num_experts, topk = c.num_experts_per_token, ei = c.expert_intermediate_size;
+  std::vector<uint32_t> idx(topk);
+  std::vector<float> wts(topk);
+  orc_moe_route(x, (const float*)L.router->data, hidden, ne, topk, 0, idx.data(), wts.data());
+  for (size_t i = 0; i < hidden; i++) out[i] = 0.0f;
+  std::vector<float> g(ei), gs(ei), u(ei), inter(ei), eo(hidden);
+  for (size_t s = 0; s < topk; s++) {
+    const ExpertRef& E = L.experts[idx[s]];
+    if (raw_vec_mat(m, E.gate_type, E.gate, x, g.data(), hidden, ei)) return 1;
+    orc_silu(g.data(), gs.data(), ei);
+    if (raw_vec_mat(m, E.up_type, E.up, x, u.data(), hidden, ei)) return 1;
+    for (size_t i = 0; i < ei; i++) inter[i] = gs[i] * u[i];
+    if (raw_vec_mat(m, E.down_type, E.down, inter.data(), eo.data(), ei, hidden)) return 1;
+    for (size_t i = 0; i < hidden; i++) out[i] += wts[s] * eo[i];  // moe.rs:363-368
+  }
+  return 0;
+}
+
+// TransformerLayer::forward, serial-residual branch (layers.rs:1082-1245)
+int layer_forward(orc_model* m, size_t li, std::vector<float>& hidden, size_t pos) {
+  const orc_config& c = m->cfg;
+  const LayerRef& L = m->layers[li];
+  size_t hs = c.hidden_size;
+  std::vector<float> norm(hs), h(hs), ffn_norm(hs), ffn_out(hs);
+  orc_rms_norm(hidden.data(), (const float*)L.attn_norm->data, c.norm_eps, norm.data(), hs);  // 1095-1096
+  if (attention_forward(m, li, norm.data(), pos, h.data())) return 1;
+  for (size_t i = 0; i < hs; i++) h[i] += hidden[i];  // 1201-1208
+  orc_rms_norm(h.data(), (const float*)L.ffn_norm->data, c.norm_eps, ffn_norm.data(), hs);  // 1210-1211
+  int rc = L.router ? moe_forward(m, L, ffn_norm.data(), ffn_out.data())
+                    : dense_ffn_forward(m, L, ffn_norm.data(), ffn_out.data());
+  if (rc) return 1;
+  for (size_t i = 0; i < hs; i++) ffn_out[i] += h[i];  // 1235-1241
+  hidden.swap(ffn_out);
+  return 0;
+}
+
+int dequant_embeddings(orc_model* m, std::vector<float>& dst) {  // llama.rs:181-193
+  const TensorRef* t = m->token_embd;
+  dst.resize(t->numel());
+  if (t->type == ORC_F32) {
+    std::memcpy(dst.data(), t->data, dst.size() * 4);
+    return 0;
+  }
+  size_t bs = orc_block_size(t->type), bb = orc_block_bytes(t->type);
+  if (!bs) return fail(m, "unsupported embedding dtype");
+  size_t nblk = dst.size() / bs;
+  int bad = 0;
+  orc_parallel_for(nblk, 4096, [&](size_t b0, size_t b1) {
+    if (orc_dequantize(t->type, t->data + b0 * bb, (b1 - b0) * bs, dst.data() + b0 * bs)) bad = 1;
+  });
+  return bad ? fail(m, "embedding dequantize failed") : 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+orc_model* orc_model_create(const orc_config* cfg) {
+  orc_model* m = new orc_model();
+  m->cfg = *cfg;
+  return m;
+}
+
+void orc_model_destroy(orc_model* m) { delete m; }
+
+const char* orc_model_last_error(const orc_model* m) { return m->err.c_str(); }
+
+int orc_model_add_tensor(orc_model* m, const char* name, int type, const uint64_t ne[4], const void* data,
+                         size_t nbytes, int borrow) {
+  if (m->finalized) return fail(m, "add_tensor after finalize");
+  size_t bs = orc_block_size(type), bb = orc_block_bytes(type);
+  if (!bs) return fail(m, std::string("unsupported dtype for ") + name);
+  TensorRef t;
+  t.type = type;
+  for (int i = 0; i < 4; i++) t.ne[i] = ne[i];
+  size_t numel = t.numel();
+  if (ne[0] % bs || numel / bs * bb != nbytes) return fail(m, std::string("byte size mismatch for ") + name);
+  t.nbytes = nbytes;
+  TensorRef& slot = m->tensors[name];
+  slot = std::move(t);
+  if (borrow) {
+    slot.data = (const uint8_t*)data;
+  } else {
+    slot.owned.assign((const uint8_t*)data, (const uint8_t*)data + nbytes);
+    slot.data = slot.owned.data();
+  }
+  return 0;
+}
+
+int orc_model_finalize(orc_model* m) {
+  const orc_config& c = m->cfg;
+  m->token_embd = find(m, "token_embd.weight");
+  if (!m->token_embd) return fail(m, "missing token_embd.weight");
+  m->output_norm = find(m, "output_norm.weight");
+  if (!m->output_norm) return fail(m, "missing output_norm.weight");
+  // tied output: reuse token_embd.weight when output.weight is absent (loader.rs:348-355)
+  m->output.w = find(m, "output.weight");
+  if (!m->output.w) m->output.w = m->token_embd;
+  m->output.bias = nullptr;
+  m->output.in_f = (size_t)m->output.w->ne[0];
+  m->output.out_f = (size_t)m->output.w->ne[1];
+  m->layers.assign(c.num_layers, LayerRef());
+  for (uint32_t i = 0; i < c.num_layers; i++) {
+    LayerRef& L = m->layers[i];
+    std::string p = "blk." + std::to_string(i) + ".";
+    L.attn_norm = find(m, p + "attn_norm.weight");
+    L.ffn_norm = find(m, p + "ffn_norm.weight");
+    if (!L.attn_norm || !L.ffn_norm) return fail(m, "missing norm weights in " + p);
+    if (bind_linear(m, L.wq, p + "attn_q", true) || bind_linear(m, L.wk, p + "attn_k", true) ||
+        bind_linear(m, L.wv, p + "attn_v", true) || bind_linear(m, L.wo, p + "attn_output", true))
+      return 1;
+    L.router = find(m, p + "ffn_gate_inp.weight");
+    if (L.router) {
+      if (L.router->type != ORC_F32) return fail(m, "router weight must be F32 (moe.rs:132-135)");
+      const TensorRef* ge = find(m, p + "ffn_gate_exps.weight");
+      const TensorRef* ue = find(m, p + "ffn_up_exps.weight");
+      const TensorRef* de = find(m, p + "ffn_down_exps.weight");
+      if (!ge || !ue || !de) return fail(m, "missing expert stacks in " + p);
+      // 3-D [in, out, n_expert], expert outermost: expert e = e-th contiguous slice (loader.rs:1256-1303)
+      L.experts.resize(c.num_experts);
+      size_t gs = ge->nbytes / c.num_experts, us = ue->nbytes / c.num_experts, ds = de->nbytes / c.num_experts;
+      for (uint32_t e = 0; e < c.num_experts; e++) {
+        L.experts[e] = ExpertRef{ge->data + e * gs, ue->data + e * us, de->data + e * ds, ge->type, ue->type, de->type};
+      }
+    } else {
+      if (bind_linear(m, L.gate, p + "ffn_gate", true) || bind_linear(m, L.up, p + "ffn_up", true) ||
+          bind_linear(m, L.down, p + "ffn_down", true))
+        return 1;
+    }
+  }
+  size_t kv = (size_t)c.num_kv_heads * c.max_seq_len * c.head_dim;
+  m->k_cache.assign(c.num_layers, std::vector<float>());
+  m->v_cache.assign(c.num_layers, std::vector<float>());
+  for (uint32_t i = 0; i < c.num_layers; i++) {
+    m->k_cache[i].assign(kv, 0.0f);
+    m->v_cache[i].assign(kv, 0.0f);
+  }
+  m->last_hidden.assign(c.hidden_size, 0.0f);
+  m->finalized = true;
+  return 0;
+}
+
+void orc_model_reset(orc_model* m) { m->position = 0; }  // KVCache::reset (model/mod.rs:110-117): O(1)
+size_t orc_model_position(const orc_model* m) { return m->position; }
+
+int orc_model_forward(orc_model* m, const uint32_t* tokens, size_t n_tokens, float* logits, int faithful_embedding) {
+  if (!m->finalized) return fail(m, "forward before finalize");
+  const orc_config& c = m->cfg;
+  if (n_tokens == 0) return fail(m, "No tokens to process");
+  if (m->position + n_tokens > c.max_seq_len) return fail(m, "context length exceeded");  // llama.rs:280-286
+  size_t hs = c.hidden_size;
+  std::vector<float> scratch;
+  const std::vector<float>* table = &m->embd_f32;
+  if (faithful_embedding) {  // llama.rs:288: whole table, every call
+    if (dequant_embeddings(m, scratch)) return 1;
+    table = &scratch;
+  } else if (m->embd_f32.empty()) {
+    if (dequant_embeddings(m, m->embd_f32)) return 1;
+  }
+  std::vector<std::vector<float>> hiddens(n_tokens);
+  for (size_t t = 0; t < n_tokens; t++) {  // llama.rs:293-307
+    if (tokens[t] >= c.vocab_size) return fail(m, "token id exceeds vocab size");
+    const float* src = table->data() + (size_t)tokens[t] * hs;
+    hiddens[t].assign(src, src + hs);
+  }
+  for (uint32_t li = 0; li < c.num_layers; li++)  // llama.rs:327-345: layer-major over the tokens
+    for (size_t t = 0; t < n_tokens; t++)
+      if (layer_forward(m, li, hiddens[t], m->position + t)) return 1;
+  m->position += n_tokens;
+  m->last_hidden = hiddens.back();
+  // compute_logits (llama.rs:247-266)
+  std::vector<float> normed(hs);
+  orc_rms_norm(hiddens.back().data(), (const float*)m->output_norm->data, c.norm_eps, normed.data(), hs);
+  return linear_forward(m, m->output, normed.data(), logits);
+}
+
+int orc_model_last_hidden(const orc_model* m, float* out) {
+  std::memcpy(out, m->last_hidden.data(), m->last_hidden.size() * 4);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+/*
+ * oracle/oracle.h — C ABI of the CPU parity oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This library is a CPU restatement of the arithmetic of the
+ * reference's CPU backend (Lexmata/llama-gguf v0.14.0) for the single-stream decode hot
+ * path.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load
+ * it, and only as the checker / timed CPU baseline.  The product (llama-gguf_amd/) never
+ * links, loads or calls it.
+ *
+ * Pinning status: every function is checked against the known-answer tests the reference's
+ * own test-suite holds for this path (tests/test_oracle_kat.py lists each one with its
+ * reference file:line).  The reference holds NO golden vector for any K-quant block, for a
+ * fused quantized dot or for a whole forward pass, and the reference (Rust) cannot be built
+ * in this image; for those, parity is pinned only by this restatement plus the
+ * self-consistency identity dot_qX(blocks, x) == sum(dequantize_qX(blocks) * x).
+ *
+ * Each function cites the reference file:line (relative to /root/reference) it follows.
+ */
+#ifndef LLAMA_GGUF_ORACLE_H
+#define LLAMA_GGUF_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml type ids (src/gguf/constants.rs:92-126) */
+enum {
+  ORC_F32 = 0, ORC_F16 = 1, ORC_Q4_0 = 2, ORC_Q4_1 = 3, ORC_Q5_0 = 6, ORC_Q5_1 = 7,
+  ORC_Q8_0 = 8, ORC_Q8_1 = 9, ORC_Q2_K = 10, ORC_Q3_K = 11, ORC_Q4_K = 12, ORC_Q5_K = 13,
+  ORC_Q6_K = 14, ORC_Q8_K = 15, ORC_BF16 = 30
+};
+
+/* dot_f32 ISA variant (src/backend/cpu/simd.rs:80-100 dispatches at run time) */
+enum { ORC_ISA_AUTO = 0, ORC_ISA_SCALAR = 1, ORC_ISA_AVX2 = 2, ORC_ISA_AVX512 = 3 };
+
+void orc_set_isa(int isa);      /* AUTO = what the reference would pick on this host */
+int orc_get_isa(void);          /* resolved ISA (never AUTO) */
+void orc_set_threads(int n);    /* worker threads for per-output-column parallel loops (rayon stand-in) */
+int orc_get_threads(void);
+
+size_t orc_block_size(int type);  /* elements per block, 0 if unknown */
+size_t orc_block_bytes(int type); /* bytes per block, 0 if unknown */
+
+uint16_t orc_f32_to_f16(float f);
+float orc_f16_to_f32(uint16_t h);
+
+/* n = number of elements, must be a multiple of the block size. Return 0 on success. */
+int orc_quantize(int type, const float* in, size_t n, void* out);
+int orc_dequantize(int type, const void* in, size_t n, float* out);
+
+/* fused quantized dot (simd.rs:931-1166); returns NaN for types without a fused dot */
+float orc_dot_q(int type, const void* blocks, const float* x, size_t k);
+int orc_has_fused_dot(int type);
+float orc_dot_f32(const float* a, const float* b, size_t n);
+
+/* out[j] = sum_i x[i] * W[i,j];  W = n rows of k/bs blocks (ops.rs:1008-1039,1123-1199) */
+int orc_vec_mat_q(int type, const void* w, const float* x, float* out, size_t k, size_t n);
+/* f32 weights, strictly sequential sum (ops.rs:959-1002) */
+void orc_vec_mat_f32(const float* w, const float* x, float* out, size_t k, size_t n);
+
+void orc_rms_norm(const float* x, const float* w, float eps, float* out, size_t n);
+void orc_rope(float* q, float* k, size_t n_heads, size_t n_kv_heads, size_t seq_len,
+              size_t head_dim, size_t pos, float freq_base, float freq_scale, int use_neox);
+void orc_attention_cached(const float* q, const float* k_cache, const float* v_cache, float* out,
+                          size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_seq_len,
+                          float scale, size_t kv_len);
+void orc_softmax_inplace(float* x, size_t n);
+void orc_silu(const float* x, float* out, size_t n);
+void orc_silu_mul_inplace(float* gate, const float* up, size_t n);
+float orc_max_f32(const float* x, size_t n);
+void orc_axpy_f32(float alpha, const float* x, float* y, size_t n);
+
+/* bench arg-max (main.rs:1815-1821): last maximal index */
+uint32_t orc_argmax_last(const float* logits, size_t n);
+/* Sampler greedy branch (sampling/mod.rs:224-242): softmax, then last maximal index */
+uint32_t orc_greedy_sample(const float* logits, size_t n);
+
+/* MoE router (moe.rs:128-198): w is [n_experts][hidden] f32. */
+void orc_moe_route(const float* h, const float* w, size_t hidden, size_t n_experts, size_t top_k,
+                   int normalize, uint32_t* idx_out, float* weight_out);
+
+/* ---------------- whole-model forward (llama.rs:275-362) ---------------- */
+
+typedef struct orc_config {
+  uint32_t hidden_size, intermediate_size, num_layers, num_heads, num_kv_heads, head_dim;
+  uint32_t vocab_size, max_seq_len;
+  uint32_t num_experts, num_experts_per_token, expert_intermediate_size;
+  uint32_t use_neox_rope;
+  float norm_eps, rope_freq_base, rope_freq_scale;
+} orc_config;
+
+typedef struct orc_model orc_model;
+
+orc_model* orc_model_create(const orc_config* cfg);
+void orc_model_destroy(orc_model* m);
+/* GGUF tensor names (blk.{i}.attn_q.weight ...); ne = GGML dims (dim 0 fastest).
+ * borrow != 0: the oracle keeps the pointer (caller keeps the bytes alive); else it copies. */
+int orc_model_add_tensor(orc_model* m, const char* name, int type, const uint64_t ne[4],
+                         const void* data, size_t nbytes, int borrow);
+int orc_model_finalize(orc_model* m);
+const char* orc_model_last_error(const orc_model* m);
+/* Model::forward(tokens, ctx): layer-major over the tokens, logits of the last token.
+ * faithful_embedding != 0 re-dequantizes the whole embedding table on every call like
+ * llama.rs:288 does (timing fidelity only; the values are identical). */
+int orc_model_forward(orc_model* m, const uint32_t* tokens, size_t n_tokens, float* logits,
+                      int faithful_embedding);
+void orc_model_reset(orc_model* m);
+size_t orc_model_position(const orc_model* m);
+/* debug taps: hidden state after the last forward's final layer (pre-norm) */
+int orc_model_last_hidden(const orc_model* m, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

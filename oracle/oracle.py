@@ -1,0 +1,275 @@
+"""ctypes binding of the CPU parity oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg; the product package never imports this module (see oracle/oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+# ggml type ids (reference: src/gguf/constants.rs:92-126)
+F32, F16, Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1 = 0, 1, 2, 3, 6, 7, 8, 9
+Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K, BF16 = 10, 11, 12, 13, 14, 15, 30
+ISA_AUTO, ISA_SCALAR, ISA_AVX2, ISA_AVX512 = 0, 1, 2, 3
+
+QUANT_TYPES = (Q4_0, Q4_1, Q5_0, Q5_1, Q8_0, Q8_1, Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, Q8_K)
+TYPE_NAMES = {F32: "F32", F16: "F16", Q4_0: "Q4_0", Q4_1: "Q4_1", Q5_0: "Q5_0", Q5_1: "Q5_1", Q8_0: "Q8_0",
+              Q8_1: "Q8_1", Q2_K: "Q2_K", Q3_K: "Q3_K", Q4_K: "Q4_K", Q5_K: "Q5_K", Q6_K: "Q6_K", Q8_K: "Q8_K",
+              BF16: "BF16"}
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/liboracle.so with the committed Makefile (g++, seconds)."""
+    srcs = [os.path.join(_HERE, f) for f in ("quant.cpp", "ops.cpp", "model.cpp", "oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+        "vocab_size", "max_seq_len", "num_experts", "num_experts_per_token", "expert_intermediate_size",
+        "use_neox_rope")] + [(n, C.c_float) for n in ("norm_eps", "rope_freq_base", "rope_freq_scale")]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    f32p, u32p, vp, sz = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t
+    sig = {
+        "orc_set_isa": (None, [C.c_int]), "orc_get_isa": (C.c_int, []),
+        "orc_set_threads": (None, [C.c_int]), "orc_get_threads": (C.c_int, []),
+        "orc_block_size": (sz, [C.c_int]), "orc_block_bytes": (sz, [C.c_int]),
+        "orc_f32_to_f16": (C.c_uint16, [C.c_float]), "orc_f16_to_f32": (C.c_float, [C.c_uint16]),
+        "orc_quantize": (C.c_int, [C.c_int, vp, sz, vp]), "orc_dequantize": (C.c_int, [C.c_int, vp, sz, vp]),
+        "orc_dot_q": (C.c_float, [C.c_int, vp, vp, sz]), "orc_has_fused_dot": (C.c_int, [C.c_int]),
+        "orc_dot_f32": (C.c_float, [vp, vp, sz]),
+        "orc_vec_mat_q": (C.c_int, [C.c_int, vp, vp, vp, sz, sz]),
+        "orc_vec_mat_f32": (None, [vp, vp, vp, sz, sz]),
+        "orc_rms_norm": (None, [vp, vp, C.c_float, vp, sz]),
+        "orc_rope": (None, [vp, vp, sz, sz, sz, sz, sz, C.c_float, C.c_float, C.c_int]),
+        "orc_attention_cached": (None, [vp, vp, vp, vp, sz, sz, sz, sz, C.c_float, sz]),
+        "orc_softmax_inplace": (None, [vp, sz]), "orc_silu": (None, [vp, vp, sz]),
+        "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]),
+        "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
+        "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
+        "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),
+        "orc_model_create": (vp, [C.POINTER(Config)]), "orc_model_destroy": (None, [vp]),
+        "orc_model_add_tensor": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_uint64), vp, sz, C.c_int]),
+        "orc_model_finalize": (C.c_int, [vp]), "orc_model_last_error": (C.c_char_p, [vp]),
+        "orc_model_forward": (C.c_int, [vp, vp, sz, vp, C.c_int]),
+        "orc_model_reset": (None, [vp]), "orc_model_position": (sz, [vp]),
+        "orc_model_last_hidden": (C.c_int, [vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def _p(a: np.ndarray) -> int:
+    return a.ctypes.data
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def block_size(t: int) -> int:
+    return lib().orc_block_size(t)
+
+
+def block_bytes(t: int) -> int:
+    return lib().orc_block_bytes(t)
+
+
+def nbytes_for(t: int, n_elems: int) -> int:
+    return n_elems // block_size(t) * block_bytes(t)
+
+
+def set_isa(isa: int) -> None:
+    lib().orc_set_isa(isa)
+
+
+def get_isa() -> int:
+    return lib().orc_get_isa()
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(n)
+
+
+def quantize(t: int, x) -> np.ndarray:
+    x = _f32(x).ravel()
+    out = np.zeros(nbytes_for(t, x.size), dtype=np.uint8)
+    if lib().orc_quantize(t, _p(x), x.size, _p(out)):
+        raise ValueError("orc_quantize failed")
+    return out
+
+
+def dequantize(t: int, raw: np.ndarray, n_elems: int) -> np.ndarray:
+    raw = np.ascontiguousarray(raw)
+    out = np.empty(n_elems, dtype=np.float32)
+    if lib().orc_dequantize(t, _p(raw), n_elems, _p(out)):
+        raise ValueError("orc_dequantize failed")
+    return out
+
+
+def dot_q(t: int, raw: np.ndarray, x) -> float:
+    x = _f32(x)
+    raw = np.ascontiguousarray(raw)
+    return float(lib().orc_dot_q(t, _p(raw), _p(x), x.size))
+
+
+def dot_f32(a, b) -> float:
+    a, b = _f32(a), _f32(b)
+    return float(lib().orc_dot_f32(_p(a), _p(b), a.size))
+
+
+def vec_mat_q(t: int, raw: np.ndarray, x, n: int) -> np.ndarray:
+    x = _f32(x)
+    raw = np.ascontiguousarray(raw)
+    out = np.empty(n, dtype=np.float32)
+    if lib().orc_vec_mat_q(t, _p(raw), _p(x), _p(out), x.size, n):
+        raise ValueError("orc_vec_mat_q failed")
+    return out
+
+
+def vec_mat_f32(w, x, n: int) -> np.ndarray:
+    w, x = _f32(w).ravel(), _f32(x)
+    out = np.empty(n, dtype=np.float32)
+    lib().orc_vec_mat_f32(_p(w), _p(x), _p(out), x.size, n)
+    return out
+
+
+def rms_norm(x, w, eps: float) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    out = np.empty_like(x)
+    lib().orc_rms_norm(_p(x), _p(w), eps, _p(out), x.size)
+    return out
+
+
+def rope(q, k, pos: int, freq_base: float, freq_scale: float, neox: bool):
+    """q: [n_heads, seq, d], k: [n_kv, seq, d]; returns rotated copies."""
+    q, k = _f32(q).copy(), _f32(k).copy()
+    lib().orc_rope(_p(q), _p(k), q.shape[0], k.shape[0], q.shape[1], q.shape[2], pos, freq_base, freq_scale,
+                   int(neox))
+    return q, k
+
+
+def attention_cached(q, k_cache, v_cache, scale: float, kv_len: int) -> np.ndarray:
+    """q: [n_heads, d]; caches: [n_kv, max_seq, d]."""
+    q, k_cache, v_cache = _f32(q), _f32(k_cache), _f32(v_cache)
+    out = np.empty_like(q)
+    lib().orc_attention_cached(_p(q), _p(k_cache), _p(v_cache), _p(out), q.shape[0], k_cache.shape[0], q.shape[1],
+                               k_cache.shape[1], scale, kv_len)
+    return out
+
+
+def softmax(x) -> np.ndarray:
+    x = _f32(x).copy()
+    lib().orc_softmax_inplace(_p(x), x.size)
+    return x
+
+
+def silu(x) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_silu(_p(x), _p(out), x.size)
+    return out
+
+
+def silu_mul(gate, up) -> np.ndarray:
+    g, u = _f32(gate).copy(), _f32(up)
+    lib().orc_silu_mul_inplace(_p(g), _p(u), g.size)
+    return g
+
+
+def argmax_last(v) -> int:
+    v = _f32(v)
+    return int(lib().orc_argmax_last(_p(v), v.size))
+
+
+def greedy_sample(v) -> int:
+    v = _f32(v)
+    return int(lib().orc_greedy_sample(_p(v), v.size))
+
+
+def moe_route(h, w, n_experts: int, top_k: int, normalize: bool = False):
+    h, w = _f32(h), _f32(w).ravel()
+    idx = np.zeros(top_k, dtype=np.uint32)
+    wt = np.zeros(top_k, dtype=np.float32)
+    lib().orc_moe_route(_p(h), _p(w), h.size, n_experts, top_k, int(normalize), _p(idx), _p(wt))
+    return idx, wt
+
+
+class Model:
+    """The reference's ``LlamaModel`` + ``InferenceContext`` as one CPU object (llama.rs:275-362)."""
+
+    def __init__(self, cfg: dict):
+        self._cfg = Config(**{k: cfg[k] for k, _ in Config._fields_ if k in cfg})
+        self._h = lib().orc_model_create(C.byref(self._cfg))
+        self._keep = []
+        self.vocab_size = cfg["vocab_size"]
+        self.hidden_size = cfg["hidden_size"]
+
+    def add_tensor(self, name: str, t: int, ne, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data)
+        self._keep.append(data)  # borrowed by the oracle
+        ne4 = (C.c_uint64 * 4)(*(list(ne) + [0] * (4 - len(ne))))
+        if lib().orc_model_add_tensor(self._h, name.encode(), t, ne4, _p(data), data.nbytes, 1):
+            raise ValueError(self.last_error())
+
+    def finalize(self) -> None:
+        if lib().orc_model_finalize(self._h):
+            raise ValueError(self.last_error())
+
+    def last_error(self) -> str:
+        return lib().orc_model_last_error(self._h).decode()
+
+    def forward(self, tokens, faithful_embedding: bool = False) -> np.ndarray:
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+        logits = np.empty(self.vocab_size, dtype=np.float32)
+        if lib().orc_model_forward(self._h, _p(toks), toks.size, _p(logits), int(faithful_embedding)):
+            raise ValueError(self.last_error())
+        return logits
+
+    def last_hidden(self) -> np.ndarray:
+        out = np.empty(self.hidden_size, dtype=np.float32)
+        lib().orc_model_last_hidden(self._h, _p(out))
+        return out
+
+    def reset(self) -> None:
+        lib().orc_model_reset(self._h)
+
+    @property
+    def position(self) -> int:
+        return lib().orc_model_position(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            lib().orc_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
