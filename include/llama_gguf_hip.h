@@ -1,0 +1,207 @@
+/*
+ * include/llama_gguf_hip.h — C ABI of the MI355X (gfx950) GPU-resident decode engine for llama-gguf.
+ *
+ * This is the drop-in boundary.  The reference (Lexmata/llama-gguf v0.14.0, Rust; paths below are
+ * relative to /root/reference) talks to every GPU engine through
+ *
+ *     pub trait GpuInference: Send {                       // src/backend/mod.rs:283-296
+ *         fn forward(&mut self, token_id: u32) -> BackendResult<Vec<f32>>;
+ *         fn prefill_token(&mut self, token_id: u32) -> BackendResult<()>;
+ *         fn reset(&mut self);
+ *         fn position(&self) -> usize;
+ *     }
+ *     pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>
+ *                                                          // src/backend/cuda/gpu_only.rs:426
+ *
+ * and adapts it to `trait Model` with GpuModelWrapper (src/backend/mod.rs:302-364).  A Rust
+ * `impl GpuInference for HipGpuInference` binds the lgh_* entry points below 1:1 (binding shown in
+ * INTEGRATION.md); each declaration cites the reference item it replaces.
+ *
+ * Conventions: plain pointers and sizes, opaque handle, `int` status (0 = ok).  Status codes map
+ * 1:1 onto the reference's BackendError variants (src/backend/error.rs:3-37).  The library keeps no
+ * thread-local state and binds its device on every call, so a context may be used from any one
+ * thread at a time (the reference serialises access with a Mutex, src/backend/mod.rs:303,328-332).
+ * All tensor payloads are handed over in NATIVE GGUF order (a weight [in, out] is `out` rows of
+ * in/block_size blocks, src/backend/cpu/ops.rs:1120-1122); the library owns any device re-layout.
+ */
+#ifndef LLAMA_GGUF_HIP_H
+#define LLAMA_GGUF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* BackendError variants, src/backend/error.rs:3-37 */
+typedef enum lgh_status {
+  LGH_OK = 0,
+  LGH_NOT_AVAILABLE = 1,         /* BackendError::NotAvailable         (no HIP device) */
+  LGH_SHAPE_MISMATCH = 2,        /* BackendError::ShapeMismatch */
+  LGH_DTYPE_MISMATCH = 3,        /* BackendError::DTypeMismatch */
+  LGH_UNSUPPORTED_DTYPE = 4,     /* BackendError::UnsupportedDType */
+  LGH_UNSUPPORTED = 5,           /* BackendError::Unsupported */
+  LGH_INVALID_ARGUMENT = 6,      /* BackendError::InvalidArgument      (incl. pos >= max_seq_len) */
+  LGH_TENSOR_ERROR = 7,          /* BackendError::Tensor(_) */
+  LGH_INITIALIZATION_FAILED = 8, /* BackendError::InitializationFailed */
+  LGH_ALLOCATION_FAILED = 9,     /* BackendError::AllocationFailed */
+  LGH_OPERATION_FAILED = 10      /* BackendError::OperationFailed      (launch / sync / copy) */
+} lgh_status;
+
+/* ggml type ids, src/gguf/constants.rs:92-126 */
+typedef enum lgh_ggml_type {
+  LGH_TYPE_F32 = 0, LGH_TYPE_F16 = 1, LGH_TYPE_Q4_0 = 2, LGH_TYPE_Q4_1 = 3, LGH_TYPE_Q5_0 = 6,
+  LGH_TYPE_Q5_1 = 7, LGH_TYPE_Q8_0 = 8, LGH_TYPE_Q8_1 = 9, LGH_TYPE_Q2_K = 10, LGH_TYPE_Q3_K = 11,
+  LGH_TYPE_Q4_K = 12, LGH_TYPE_Q5_K = 13, LGH_TYPE_Q6_K = 14, LGH_TYPE_Q8_K = 15, LGH_TYPE_BF16 = 30
+} lgh_ggml_type;
+
+/* What GpuOnlyInference::from_model reads out of ModelConfig and the per-layer Attention scalars
+ * (src/backend/cuda/gpu_only.rs:488-502, 527-533, 555-572; src/model/layers.rs:262-298). */
+typedef struct lgh_model_desc {
+  uint32_t struct_size;              /* sizeof(lgh_model_desc), for ABI evolution */
+  uint32_t hidden_size;
+  uint32_t intermediate_size;
+  uint32_t num_layers;               /* layers of the WHOLE model */
+  uint32_t num_heads;
+  uint32_t num_kv_heads;
+  uint32_t head_dim;                 /* key_length == value_length */
+  uint32_t vocab_size;
+  uint32_t max_seq_len;              /* KV capacity (the engine's gpu_seq_len, src/engine.rs:554-564) */
+  uint32_t num_experts;              /* 0 = dense FFN */
+  uint32_t num_experts_per_token;
+  uint32_t expert_intermediate_size;
+  uint32_t use_neox_rope;            /* RopeType::NeoX vs Normal, src/model/loader.rs:145-162 */
+  float norm_eps;
+  float rope_freq_base;
+  float rope_freq_scale;
+  int32_t device_id;                 /* HIP device ordinal */
+  /* pipeline stage (src/distributed/pipeline.rs:50-96 partitioning): this context owns layers
+   * [layer_begin, layer_end); 0,0 means all.  The first stage owns the embedding, the last one the
+   * final norm + output projection. */
+  uint32_t layer_begin;
+  uint32_t layer_end;
+  uint32_t flags;                    /* LGH_FLAG_* */
+} lgh_model_desc;
+
+enum {
+  LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
+  LGH_FLAG_ATTN_SPLITS_SHIFT = 8     /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
+};
+
+typedef struct lgh_ctx lgh_ctx;
+
+/* kernel classes reported by lgh_get_stats (profiling mode) */
+enum {
+  LGH_K_EMBED = 0, LGH_K_QKV = 1, LGH_K_ATTN = 2, LGH_K_ATTN_COMBINE = 3, LGH_K_WO = 4, LGH_K_GATEUP = 5,
+  LGH_K_DOWN = 6, LGH_K_ROUTER = 7, LGH_K_OUTPUT = 8, LGH_K_ARGMAX = 9, LGH_K_MISC = 10, LGH_K_COUNT = 16
+};
+
+typedef struct lgh_stats {
+  uint64_t weight_bytes;             /* quantized + f32 weight bytes resident in HBM */
+  uint64_t kv_bytes;                 /* KV cache bytes */
+  uint64_t scratch_bytes;
+  uint64_t tokens_processed;
+  uint64_t graph_nodes;              /* kernel nodes in one decode-step graph */
+  /* profiling mode only: per-class launches, device time (hipEvent) and algorithmic HBM bytes */
+  uint64_t k_launches[LGH_K_COUNT];
+  double k_time_us[LGH_K_COUNT];
+  uint64_t k_alg_bytes[LGH_K_COUNT];
+  /* algorithmic bytes of one decode step at the current position (SURVEY.md §8d formula) */
+  uint64_t step_alg_bytes;
+} lgh_stats;
+
+/* ---- lifecycle: replaces GpuOnlyInference::from_model (src/backend/cuda/gpu_only.rs:426-726) ---- */
+
+/* Number of HIP devices visible (0 when none / no driver).  Never fails. */
+int lgh_device_count(void);
+
+/* CudaDevice::new + scratch/KV allocation (gpu_only.rs:438-440, 527-598). */
+int lgh_create(const lgh_model_desc* desc, lgh_ctx** out);
+
+/* upload_model_weights (src/backend/cuda/dequant_weights.rs:244-505): one call per tensor, GGUF name
+ * (`token_embd.weight`, `blk.{i}.attn_q.weight`, ... `blk.{i}.ffn_gate_exps.weight` or the loader's
+ * per-expert `blk.{i}.ffn_gate.{e}.weight`, `output_norm.weight`, `output.weight`), GGML dims (dim 0
+ * fastest), host bytes in native GGUF order.  Tensors of layers outside this stage are ignored. */
+int lgh_upload_tensor(lgh_ctx* ctx, const char* gguf_name, uint32_t ggml_type, const uint64_t ne[4],
+                      const void* host_bytes, size_t nbytes);
+
+/* Validates that every tensor the stage needs is present, builds RoPE tables and the hipGraphs. */
+int lgh_finalize(lgh_ctx* ctx);
+
+/* impl Drop */
+void lgh_destroy(lgh_ctx* ctx);
+
+/* ---- GpuInference (src/backend/mod.rs:283-296) ---- */
+
+/* GpuInference::forward (gpu_only.rs:728-771): logits_out = vocab_size f32, caller-owned. */
+int lgh_forward(lgh_ctx* ctx, uint32_t token_id, float* logits_out);
+/* GpuInference::prefill_token (gpu_only.rs:792-806) */
+int lgh_prefill_token(lgh_ctx* ctx, uint32_t token_id);
+/* GpuOnlyInference::forward_batch minus the last token (gpu_only.rs:776-790): n prefill_tokens */
+int lgh_prefill_batch(lgh_ctx* ctx, const uint32_t* tokens, size_t n);
+/* GpuInference::reset (gpu_only.rs:808-843) — O(1): only the position is rewound (model/mod.rs:110-117) */
+void lgh_reset(lgh_ctx* ctx);
+/* GpuInference::position (gpu_only.rs:845-847) */
+size_t lgh_position(const lgh_ctx* ctx);
+
+/* forward + the bench's arg-max (src/main.rs:1812-1822; ties -> LAST maximal index) on device:
+ * only 4 bytes cross PCIe. */
+int lgh_forward_argmax(lgh_ctx* ctx, uint32_t token_id, uint32_t* next_token);
+/* n_steps of greedy decode with the token fed back ON DEVICE (the loop of src/main.rs:1812-1822);
+ * tokens_out[i] = arg-max after step i.  One host sync at the end. */
+int lgh_decode_greedy(lgh_ctx* ctx, uint32_t first_token, size_t n_steps, uint32_t* tokens_out);
+
+const char* lgh_last_error(const lgh_ctx* ctx);
+int lgh_get_stats(lgh_ctx* ctx, lgh_stats* out);
+/* on: run eagerly with hipEvent pairs around every launch and accumulate lgh_stats.k_* */
+int lgh_set_profiling(lgh_ctx* ctx, int on);
+/* Use an external HIP stream (e.g. torch's current stream) for all work; NULL = the context's own. */
+int lgh_set_stream(lgh_ctx* ctx, void* hip_stream);
+void* lgh_get_stream(lgh_ctx* ctx);
+int lgh_synchronize(lgh_ctx* ctx);
+
+/* debug tap: copy the hidden state (f32[hidden_size]) of the last processed token to host */
+int lgh_read_hidden(lgh_ctx* ctx, float* out);
+
+/* ---- pipeline stages over xGMI (replaces ShardServer::forward, src/distributed/shard.rs:377-445) ----
+ * The hop between stages is one f32[hidden_size] vector; the host side moves it with RCCL
+ * send/recv (or a peer copy) between the device buffers returned here. */
+int lgh_stage_hidden_buffer(lgh_ctx* ctx, void** device_ptr);     /* in/out residual stream buffer */
+/* Run this stage's layers for one token at the context's position.  First stage: embeds token_id;
+ * other stages: consume the hidden buffer.  Last stage with want_logits: final norm + output
+ * projection (+ device arg-max into *next_token if non-NULL).  Asynchronous on the stream unless
+ * logits_out / next_token are requested. */
+int lgh_stage_forward(lgh_ctx* ctx, uint32_t token_id, int want_logits, float* logits_out, uint32_t* next_token);
+
+/* ---- per-op surface: the `Backend` trait ops on the path (src/backend/mod.rs:29-265), host tensors
+ * in / host tensors out, for parity tests of each kernel against the CPU backend. ---- */
+int lgh_op_dequantize(int device, uint32_t ggml_type, const void* src, size_t n_elems, float* dst);
+/* Backend::vec_mat_q / vec_mat: out[j] = sum_i x[i] * W[i,j], W = n rows of k/bs blocks */
+int lgh_op_vec_mat(int device, uint32_t ggml_type, const void* w, const float* x, float* out, size_t k, size_t n);
+int lgh_op_rms_norm(int device, const float* x, const float* w, float eps, float* out, size_t n);
+/* Backend::rope with seq_len 1: q [n_heads, d], k [n_kv_heads, d] rotated in place */
+int lgh_op_rope(int device, float* q, float* k, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t pos,
+                float freq_base, float freq_scale, int use_neox);
+/* Backend::attention_cached: caches [n_kv_heads, max_seq_len, d] */
+int lgh_op_attention_cached(int device, const float* q, const float* k_cache, const float* v_cache, float* out,
+                            size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_seq_len, float scale,
+                            size_t kv_len, int n_splits);
+/* simd::silu_mul_inplace: out = silu(gate) * up */
+int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, size_t n);
+/* fused decode kernels, for kernel-level parity: out = resid + W.(rms_norm(x)*norm_w) etc. */
+int lgh_op_norm_vec_mat(int device, uint32_t ggml_type, const void* w, const float* x, const float* norm_w, float eps,
+                        float* out, size_t k, size_t n);
+int lgh_op_swiglu_vec_mat(int device, uint32_t ggml_type, const void* w_gate, const void* w_up, const float* x,
+                          const float* norm_w, float eps, float* out, size_t k, size_t n);
+
+/* Micro-benchmark of the fused quantized mat-vec kernel on device-resident synthetic data:
+ * `iters` back-to-back launches timed with hipEvents on the launch stream.  mode 0 = plain matvec,
+ * 1 = rmsnorm prologue, 2 = gate/up SwiGLU pair.  avg_us = mean device time per launch. */
+int lgh_bench_vec_mat(int device, uint32_t ggml_type, const void* w, const void* w2, size_t k, size_t n, int mode,
+                      int iters, double* avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+// attention.hip — single-token GQA attention over the HBM-resident f32 KV cache.
+//
+// Replaces `flash_attention_cached` (src/backend/cuda/kernels.rs:1395-1458: one workgroup per query
+// head, a SERIAL loop over kv positions with two block-wide reductions per position) and follows the
+// CPU backend's `attention_cached` (src/backend/cpu/ops.rs:1479-1537): score = <q,k>*scale, softmax over
+// kv_len, out = sum_p w_p * V[p].  KV layout is the reference's [n_kv_heads, max_seq, head_dim] f32
+// (src/model/mod.rs:64-108).
+//
+// Decode attention is a latency problem at short context and an HBM stream at long context, so:
+//   * work is split over (kv head) x (n_splits) workgroups, each with 4 waves; positions are dealt
+//     round-robin so every workgroup has work from the first cached token on;
+//   * the G = n_heads/n_kv_heads query heads of a kv group are processed together: one 16-byte K/V load
+//     per lane serves all G heads (GQA reuse), K/V rows go straight to VGPRs (no LDS staging);
+//   * a row of head_dim floats is spread over head_dim/4 lanes, so one wave-instruction covers 2 rows
+//     (d=128) or 4 rows (d=64), fully coalesced 512-byte / 256-byte rows;
+//   * online softmax per lane group; partial (m, l, acc) states merge in registers, then LDS, then in
+//     a tiny combine kernel across splits.
+// The reference CPU path skips softmax weights <= 1e-8 (ops.rs:1529); like the reference's own GPU
+// kernel this one does not (each skipped term is < 1e-8 of the output scale).
+#include "device_utils.h"
+
+namespace lgh {
+
+constexpr float kNegBig = -1e30f;
+
+template <int D, int G>
+__global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                           const float* __restrict__ vc, uint32_t max_seq, float scale,
+                                                           const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
+                                                           float* __restrict__ part_ml, float* __restrict__ part_acc) {
+  constexpr int LPR = D / 4;       // lanes per row
+  constexpr int RPW = 64 / LPR;    // rows per wave-instruction
+  __shared__ float s_ml[4][G][2];
+  __shared__ float s_acc[4][G][D];
+
+  const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sub = lane / LPR, li = lane % LPR;
+  const uint32_t kv_len = pos_ptr ? (uint32_t)(*pos_ptr + 1) : (uint32_t)kv_len_fixed;
+
+  f32x4 qv[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const f32x4*>(q + ((size_t)kvh * G + g) * D + li * 4);
+
+  float m[G], l[G];
+  f32x4 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) { m[g] = kNegBig; l[g] = 0.0f; acc[g] = (f32x4)(0.0f); }
+
+  const float* kbase = kc + (size_t)kvh * max_seq * D + li * 4;
+  const float* vbase = vc + (size_t)kvh * max_seq * D + li * 4;
+  const uint32_t stride = n_splits * 4 * RPW;
+  for (uint32_t base = (sp * 4 + wave) * RPW; base < kv_len; base += stride) {
+    const uint32_t p = base + sub;
+    const bool valid = p < kv_len;
+    const uint32_t pc = valid ? p : kv_len - 1;
+    const f32x4 k4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + (size_t)pc * D));
+    const f32x4 v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + (size_t)pc * D));
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      float s = qv[g].x * k4.x;
+      s = __builtin_fmaf(qv[g].y, k4.y, s);
+      s = __builtin_fmaf(qv[g].z, k4.z, s);
+      s = __builtin_fmaf(qv[g].w, k4.w, s);
+#pragma unroll
+      for (int off = LPR / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+      s *= scale;
+      const float mn = valid ? fmaxf(m[g], s) : m[g];
+      const float a = expf(m[g] - mn);
+      const float pe = valid ? expf(s - mn) : 0.0f;
+      l[g] = __builtin_fmaf(l[g], a, pe);
+      acc[g] = acc[g] * a + v4 * pe;
+      m[g] = mn;
+    }
+  }
+
+  // merge the RPW row slots of the wave (lanes with equal li hold the same output dims)
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float om = __shfl_xor(m[g], off, 64), ol = __shfl_xor(l[g], off, 64);
+      f32x4 oa;
+      oa.x = __shfl_xor(acc[g].x, off, 64); oa.y = __shfl_xor(acc[g].y, off, 64);
+      oa.z = __shfl_xor(acc[g].z, off, 64); oa.w = __shfl_xor(acc[g].w, off, 64);
+      const float mn = fmaxf(m[g], om);
+      const float a = expf(m[g] - mn), b = expf(om - mn);
+      l[g] = l[g] * a + ol * b;
+      acc[g] = acc[g] * a + oa * b;
+      m[g] = mn;
+    }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (li == 0) { s_ml[wave][g][0] = m[g]; s_ml[wave][g][1] = l[g]; }
+      *reinterpret_cast<f32x4*>(&s_acc[wave][g][li * 4]) = acc[g];
+    }
+  }
+  __syncthreads();
+  // merge the 4 waves; thread t handles output elements t, t+256, ...
+  const size_t pbase = ((size_t)kvh * n_splits + sp) * G;
+  for (uint32_t e = threadIdx.x; e < (uint32_t)(G * D); e += 256) {
+    const uint32_t g = e / D, dim = e % D;
+    float mn = s_ml[0][g][0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) mn = fmaxf(mn, s_ml[w][g][0]);
+    float lsum = 0.0f, a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float f = expf(s_ml[w][g][0] - mn);
+      lsum += s_ml[w][g][1] * f;
+      a += s_acc[w][g][dim] * f;
+    }
+    part_acc[(pbase + g) * D + dim] = a;
+    if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
+  }
+}
+
+// out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}
+__global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
+                                                           uint32_t g_per_kv, uint32_t head_dim, uint32_t n_splits,
+                                                           float* __restrict__ out) {
+  const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
+  float mn = kNegBig;
+  for (uint32_t s = 0; s < n_splits; s++) mn = fmaxf(mn, part_ml[(((size_t)kvh * n_splits + s) * g_per_kv + g) * 2]);
+  for (uint32_t dim = threadIdx.x; dim < head_dim; dim += blockDim.x) {
+    float lsum = 0.0f, a = 0.0f;
+    for (uint32_t s = 0; s < n_splits; s++) {
+      const size_t pi = ((size_t)kvh * n_splits + s) * g_per_kv + g;
+      const float f = expf(part_ml[pi * 2] - mn);
+      lsum += part_ml[pi * 2 + 1] * f;
+      a += part_acc[pi * head_dim + dim] * f;
+    }
+    out[(size_t)h * head_dim + dim] = a * (1.0f / lsum);  // simd.rs:718-720: multiply by 1/sum
+  }
+}
+
+template <int D, int G>
+static hipError_t attn_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale,
+                          const int* pos, int kv_len_fixed, uint32_t n_splits, float* part_ml, float* part_acc,
+                          hipStream_t st) {
+  hipLaunchKernelGGL((attn_partial_kernel<D, G>), dim3(n_kv * n_splits), dim3(256), 0, st, q, kc, vc, max_seq, scale, pos,
+                     kv_len_fixed, n_splits, part_ml, part_acc);
+  return hipGetLastError();
+}
+
+hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
+                       uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, int kv_len_fixed,
+                       uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_ATTN_CASE(DD, GG) \
+  if (head_dim == DD && g == GG)  \
+    return attn_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, kv_len_fixed, n_splits, part_ml, part_acc, st);
+  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
+  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
+#undef LGH_ATTN_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
+                               uint32_t head_dim, uint32_t n_splits, float* out, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(n_heads), dim3(head_dim >= 128 ? 128 : 64), 0, st, part_ml, part_acc,
+                     n_heads / n_kv, head_dim, n_splits, out);
+  return hipGetLastError();
+}
+
+}  // namespace lgh

@@ -1,0 +1,171 @@
+// common.h — shared declarations of the gfx950 decode engine (internal; the public ABI is
+// include/llama_gguf_hip.h).  Everything here is written for CDNA4 only: 64-lane waves, 256 CUs,
+// no portability layers.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/llama_gguf_hip.h"
+
+namespace lgh {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;
+
+// elements / bytes per block of a GGUF type (src/tensor/dtype.rs:50-108); 0 = unknown
+__host__ __device__ inline uint32_t blk_elems(int t) {
+  switch (t) {
+    case LGH_TYPE_F32: case LGH_TYPE_F16: case LGH_TYPE_BF16: return 1;
+    case LGH_TYPE_Q4_0: case LGH_TYPE_Q4_1: case LGH_TYPE_Q5_0: case LGH_TYPE_Q5_1: case LGH_TYPE_Q8_0:
+    case LGH_TYPE_Q8_1: return 32;
+    case LGH_TYPE_Q2_K: case LGH_TYPE_Q3_K: case LGH_TYPE_Q4_K: case LGH_TYPE_Q5_K: case LGH_TYPE_Q6_K:
+    case LGH_TYPE_Q8_K: return 256;
+    default: return 0;
+  }
+}
+
+__host__ __device__ inline uint32_t blk_bytes(int t) {
+  switch (t) {
+    case LGH_TYPE_F32: return 4; case LGH_TYPE_F16: case LGH_TYPE_BF16: return 2;
+    case LGH_TYPE_Q4_0: return 18; case LGH_TYPE_Q4_1: return 20; case LGH_TYPE_Q5_0: return 22;
+    case LGH_TYPE_Q5_1: return 24; case LGH_TYPE_Q8_0: return 34; case LGH_TYPE_Q8_1: return 36;
+    case LGH_TYPE_Q2_K: return 84; case LGH_TYPE_Q3_K: return 110; case LGH_TYPE_Q4_K: return 144;
+    case LGH_TYPE_Q5_K: return 176; case LGH_TYPE_Q6_K: return 210; case LGH_TYPE_Q8_K: return 292;
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device weight layouts (what lgh_upload_tensor leaves in HBM).  Byte counts equal the GGUF payload;
+// formats whose blocks are not 16-byte multiples are split into per-matrix planes so that every
+// lane load is an aligned 16-byte (or 8-byte) access.
+//
+//   Q4_K  native 144-B blocks {d,dmin,scales[12],qs[128]}                       plane0
+//   Q5_K  native 176-B blocks {d,dmin,scales[12],qh[32],qs[128]}                plane0
+//   Q6_K  plane0 ql[128]/blk, plane1 qh[64]/blk, plane2 scales[16]/blk, plane3 d(f16)/blk
+//   Q8_0  plane0 qs[32]/blk,  plane1 d(f16)/blk
+//   Q4_0  plane0 qs[16]/blk,  plane1 d(f16)/blk
+//   F32   plane0 row-major [n][k]
+// Every other GGUF type is dequantized to F32 at upload (the reference does the same for types
+// without a quantized kernel, src/backend/cuda/dequant_weights.rs:211-231).
+// ---------------------------------------------------------------------------------------------
+struct DevWeight {
+  int type = -1;            // device type: LGH_TYPE_{Q4_K,Q5_K,Q6_K,Q8_0,Q4_0,F32}
+  int src_type = -1;        // GGUF type it was uploaded as
+  uint32_t k = 0, n = 0;    // in_features, out_features (per expert for stacks)
+  uint32_t n_stack = 1;     // experts stacked along the outermost dim
+  uint8_t* base = nullptr;  // one allocation
+  const uint8_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t stack_stride[4] = {0, 0, 0, 0};  // bytes between consecutive experts, per plane
+  size_t bytes = 0;         // payload bytes (== algorithmic bytes of one full read)
+  bool present() const { return base != nullptr; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Fused mat-vec launch descriptor (passed by value as the kernel argument).
+//
+// A launch covers up to 3 SEGMENTS (e.g. Q, K, V of one layer); a workgroup belongs to exactly one
+// segment and owns `rows_per_wg` consecutive output rows of it.  A segment runs up to 4 PASSES over
+// its rows, each with its own weight matrix and input vector (gate+up share x; the two selected MoE
+// experts have different x), and the epilogue combines the per-pass results of a row.
+// Inside a workgroup, wave w works on k-slice (w % T) of row-group (w / T): a lane keeps the slice of
+// x it needs in registers for the whole kernel, so weights are the only streamed operand.
+// ---------------------------------------------------------------------------------------------
+enum MvEpilogue : int {
+  EPI_STORE = 0,       // out[row] = v0 (+bias)
+  EPI_RESID = 1,       // out[row] = v0 (+bias) + resid[row]              (layers.rs:1201-1208, 1235-1241)
+  EPI_SWIGLU = 2,      // out[row] = silu(v0) * v1                        (simd.rs:598-649)
+  EPI_ROPE_Q = 3,      // rotate pairs (2i,2i+1) at *pos, out[row]        (ops.rs:1285-1337)
+  EPI_ROPE_K = 4,      // rotate, then write into K cache row *pos        (layers.rs:577-600)
+  EPI_V_CACHE = 5,     // write into V cache row *pos
+  EPI_MOE_SWIGLU = 6,  // out[row] = silu(v0)*v1 ; out2[row] = silu(v2)*v3 (two selected experts)
+  EPI_MOE_DOWN = 7,    // out[row] = (w0*v0 + w1*v1 ...) + resid[row]     (moe.rs:363-368)
+};
+
+struct MvPass {
+  const uint8_t* plane[4];
+  const float* x;
+  const int* sel;            // optional device int: expert index; plane[i] += *sel * sel_stride[i]
+  uint64_t sel_stride[4];
+};
+
+struct MvSeg {
+  int type;                  // device weight type
+  int epi;
+  uint32_t n_rows;
+  uint32_t nblk;             // blocks per row (k / block_size)
+  uint32_t units;            // lane-units per row
+  uint32_t T, G;             // k-slices (waves per row), row-groups
+  uint32_t rows_per_wg;
+  uint32_t wg_begin;         // first workgroup of this segment
+  int npass;
+  MvPass pass[4];
+  float* out;
+  float* out2;
+  const float* resid;
+  const float* bias;
+  const float* moe_w;        // device: routing weights of the selected experts
+  uint32_t head_dim;         // RoPE / cache epilogues
+  uint32_t max_seq;
+};
+
+struct MvLaunch {
+  int nseg;
+  uint32_t k;
+  int do_norm;               // RMSNorm prologue on x (all passes share pass[0].x)
+  float eps;
+  const float* norm_w;
+  const int* pos;            // device: current position (RoPE / cache epilogues)
+  const float* rope_cs;      // [max_seq][head_dim/2][2] cos,sin
+  MvSeg seg[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (defined in the .hip files)
+// ---------------------------------------------------------------------------------------------
+struct MvPlan {               // geometry chosen by the host for one weight shape
+  uint32_t units, T, G, rows_per_wg, n_wg, threads;
+};
+
+// matvec
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan);
+hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
+hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
+                             float eps, const float* resid, hipStream_t st);
+
+// upload-time re-layout and dequantization (dst device buffers)
+hipError_t repack_launch(int src_type, const uint8_t* raw, uint8_t* dst, const uint64_t plane_off[4], uint64_t n_blocks,
+                         hipStream_t st);
+hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t n_elems, hipStream_t st);
+// dequantize row `*token` of a [vocab][hidden] table in its NATIVE GGUF layout into dst (embedding lookup)
+hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,
+                        hipStream_t st);
+
+// misc kernels
+hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st);
+hipError_t rope_launch(float* q, float* k, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, const int* pos,
+                       const float* rope_cs, int neox, hipStream_t st);
+hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint32_t n, hipStream_t st);
+hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,
+                         hipStream_t st);
+hipError_t advance_launch(int* state, hipStream_t st);
+hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
+                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st);
+
+// attention
+hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
+                       uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, int kv_len_fixed,
+                       uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
+hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
+                               uint32_t head_dim, uint32_t n_splits, float* out, hipStream_t st);
+
+// device state block: [0] token, [1] current position, [2] next position, [3] last arg-max
+enum { ST_TOKEN = 0, ST_POS = 1, ST_NEXT = 2, ST_ARGMAX = 3, ST_WORDS = 8 };
+
+}  // namespace lgh

@@ -1,0 +1,117 @@
+// engine.h — the GPU-resident decode engine behind the lgh_* C ABI (internal).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace lgh {
+
+struct LayerW {
+  bool owned = false;  // layer belongs to this pipeline stage
+  DevWeight wq, wk, wv, wo, gate, up, down;           // dense
+  DevWeight gate_exps, up_exps, down_exps;            // MoE stacks [in, out, n_expert]
+  float* attn_norm = nullptr;
+  float* ffn_norm = nullptr;
+  float* router = nullptr;                            // [n_experts][hidden] f32
+  float* bq = nullptr; float* bk = nullptr; float* bv = nullptr; float* bo = nullptr;
+  float* kcache = nullptr;
+  float* vcache = nullptr;
+  bool moe() const { return router != nullptr; }
+};
+
+enum TokenMode { MODE_PREFILL = 0, MODE_FORWARD = 1, MODE_GREEDY = 2, MODE_COUNT = 3 };
+
+struct ProfRec { int cls; hipEvent_t a, b; };
+
+}  // namespace lgh
+
+struct lgh_ctx {
+  lgh_model_desc d{};
+  int device = 0;
+  uint32_t l0 = 0, l1 = 0;
+  bool first = true, last = true;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<lgh::LayerW> layers;
+  // embedding table in native GGUF layout (row-dequantized per token) and the output projection
+  uint8_t* embd_raw = nullptr;
+  int embd_type = -1;
+  size_t embd_bytes = 0;
+  std::vector<uint8_t> embd_host;  // kept only until finalize, for a tied output projection
+  lgh::DevWeight output;
+  float* output_norm = nullptr;
+  // scratch (device)
+  float *hidden = nullptr, *xnorm = nullptr, *q = nullptr, *kv_tmp = nullptr, *attn_out = nullptr, *act = nullptr,
+        *act2 = nullptr, *logits = nullptr, *part_ml = nullptr, *part_acc = nullptr, *rope_cs = nullptr, *moe_w = nullptr,
+        *amax_v = nullptr;
+  int *moe_sel = nullptr, *state = nullptr, *amax_i = nullptr, *tok_log = nullptr;
+  uint32_t n_splits = 8;
+  // host mirrors
+  size_t pos = 0;
+  bool finalized = false;
+  bool profiling = false;
+  std::string err;
+  hipGraphExec_t graph[lgh::MODE_COUNT] = {nullptr, nullptr, nullptr};
+  uint64_t graph_nodes = 0;
+  // accounting
+  lgh_stats stats{};
+  std::vector<lgh::ProfRec> prof;
+  std::vector<void*> allocs;  // everything hipMalloc'ed by this context
+};
+
+// ---- helpers shared by engine.hip and ops_api.hip ----
+#include <cstring>
+
+struct LayoutInfo {
+  int dev_type;
+  int nplanes;
+  uint32_t bpb[4];      // bytes per block, per plane
+  uint32_t belems;      // elements per block
+};
+
+struct SegSpec {
+  int npass = 1;
+  const lgh::DevWeight* W[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float* x[4] = {nullptr, nullptr, nullptr, nullptr};
+  const int* sel[4] = {nullptr, nullptr, nullptr, nullptr};
+  int epi = lgh::EPI_STORE;
+  float* out = nullptr;
+  float* out2 = nullptr;
+  const float* resid = nullptr;
+  const float* bias = nullptr;
+  const float* moe_w = nullptr;
+};
+
+int fail(lgh_ctx* c, int status, const std::string& msg);
+int dev_alloc(lgh_ctx* c, void** p, size_t bytes);
+LayoutInfo layout_for(int src_type);
+bool fused_type(int t);
+int upload_matrix(lgh_ctx* c, lgh::DevWeight& W, int src_type, uint32_t k, uint32_t n, uint32_t n_stack, int slot,
+                  const void* host, size_t nbytes);
+int upload_f32(lgh_ctx* c, float** dst, int src_type, uint64_t n, const void* host, size_t nbytes);
+int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k);
+int linear_any(lgh_ctx* c, int cls, const lgh::DevWeight& W, const float* x, float* out, const float* norm_w,
+               const float* resid, const float* bias);
+int drain_prof(lgh_ctx* c);
+
+// ------------------------------------------------------------------------------------------------
+// launch recording (profiling mode: hipEvent pair per launch, on the launch stream)
+// ------------------------------------------------------------------------------------------------
+template <class F>
+inline int run_k(lgh_ctx* c, int cls, uint64_t alg_bytes, F&& f) {
+  lgh::ProfRec rec{cls, nullptr, nullptr};
+  if (c->profiling) {
+    if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return fail(c, LGH_OPERATION_FAILED, "hipEventCreate");
+    (void)hipEventRecord(rec.a, c->stream);
+  }
+  hipError_t e = f();
+  if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("kernel launch (class ") + std::to_string(cls) + "): " + hipGetErrorString(e));
+  if (c->profiling) {
+    (void)hipEventRecord(rec.b, c->stream);
+    c->prof.push_back(rec);
+    c->stats.k_alg_bytes[cls] += alg_bytes;
+  }
+  return LGH_OK;
+}
+

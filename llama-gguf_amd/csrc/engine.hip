@@ -1,0 +1,818 @@
+// engine.hip — GPU-resident decode engine: weight store, KV cache, per-token launch sequence,
+// hipGraph replay.  Mirrors what the reference's GpuOnlyInference does around its kernels
+// (src/backend/cuda/gpu_only.rs:426-1024) with an MI355X-first structure:
+//
+//   reference (per token)                                   here
+//   ------------------------------------------------------- ---------------------------------------------
+//   H2D embedding row from a host f32 table (849-858)        row dequantized on device from the quantized table
+//   ~20 driver calls per layer, no graph (860-1024)          5-6 launches per layer, one hipGraph replay per token
+//   norm, QKV x3, dtod, rope, kv write (865-875,1056-1281)   ONE launch: RMSNorm prologue + QKV + RoPE + cache write
+//   add + dtod after wo / down (969-978, 1012-1021)          residual add is the mat-vec epilogue, in place
+//   gate, up, silu(+alloc+dtod), mul (1605-1651)             ONE launch with a SwiGLU epilogue
+//   MoE: D2H router logits, host top-k, 3 expert matrices    router + top-k on device; experts resident in HBM and
+//   re-uploaded per expert per layer per token (1765-2011)   selected by a device-side index
+//   D2H full logits every token (764-767)                    kept for lgh_forward; lgh_decode_greedy feeds the
+//                                                            arg-max back on device
+//   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
+#include "engine.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace lgh;
+
+namespace lgh {
+hipError_t kv_store_launch(const float* k, const float* v, float* kcache, float* vcache, uint32_t n_kv, uint32_t d,
+                           uint32_t max_seq, const int* pos, hipStream_t st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+int fail(lgh_ctx* c, int status, const std::string& msg) {
+  if (c) c->err = msg;
+  return status;
+}
+
+#define HIP_TRY(c, status, expr)                                                                      \
+  do {                                                                                                \
+    hipError_t e__ = (expr);                                                                          \
+    if (e__ != hipSuccess)                                                                            \
+      return fail((c), (status), std::string(#expr) + ": " + hipGetErrorString(e__));                 \
+  } while (0)
+
+int dev_alloc(lgh_ctx* c, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 4;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) return fail(c, LGH_ALLOCATION_FAILED, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+  c->allocs.push_back(*p);
+  return LGH_OK;
+}
+
+static void dev_free_tracked(lgh_ctx* c, void* p) {
+  for (auto& a : c->allocs)
+    if (a == p) { a = c->allocs.back(); c->allocs.pop_back(); break; }
+  (void)hipFree(p);
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------
+// device layouts
+// ------------------------------------------------------------------------------------------------
+LayoutInfo layout_for(int src_type) {
+  switch (src_type) {
+    case LGH_TYPE_Q4_K: return {LGH_TYPE_Q4_K, 1, {144, 0, 0, 0}, 256};
+    case LGH_TYPE_Q5_K: return {LGH_TYPE_Q5_K, 1, {176, 0, 0, 0}, 256};
+    case LGH_TYPE_Q6_K: return {LGH_TYPE_Q6_K, 4, {128, 64, 16, 2}, 256};
+    case LGH_TYPE_Q8_0: return {LGH_TYPE_Q8_0, 2, {32, 2, 0, 0}, 32};
+    case LGH_TYPE_Q4_0: return {LGH_TYPE_Q4_0, 2, {16, 2, 0, 0}, 32};
+    default: return {LGH_TYPE_F32, 1, {4, 0, 0, 0}, 1};
+  }
+}
+
+bool fused_type(int t) {
+  return t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
+}
+
+// Upload one matrix (or expert `slot` of a stack, or the whole stack when slot < 0) given in native
+// GGUF order.  The first call for a DevWeight allocates it.
+int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n, uint32_t n_stack, int slot,
+                         const void* host, size_t nbytes) {
+  const uint32_t sbe = blk_elems(src_type), sbb = blk_bytes(src_type);
+  if (!sbe) return fail(c, LGH_UNSUPPORTED_DTYPE, "unsupported ggml type " + std::to_string(src_type));
+  if (k % sbe) return fail(c, LGH_SHAPE_MISMATCH, "in_features not a multiple of the block size");
+  const LayoutInfo li = layout_for(src_type);
+  const uint64_t per_expert_src = (uint64_t)n * (k / sbe) * sbb;
+  const uint32_t n_in_payload = slot < 0 ? n_stack : 1;
+  if (nbytes != per_expert_src * n_in_payload) return fail(c, LGH_SHAPE_MISMATCH, "tensor byte size does not match its shape");
+  const uint64_t blocks_per_expert = (uint64_t)n * (k / li.belems);
+  if (!W.present()) {
+    uint64_t off = 0;
+    uint64_t plane_off[4] = {0, 0, 0, 0};
+    for (int p = 0; p < li.nplanes; p++) {
+      plane_off[p] = off;
+      W.stack_stride[p] = blocks_per_expert * li.bpb[p];
+      off = align_up(off + W.stack_stride[p] * n_stack, 256);
+    }
+    void* base = nullptr;
+    int rc = dev_alloc(c, &base, off + 256);
+    if (rc) return rc;
+    W.base = (uint8_t*)base;
+    for (int p = 0; p < li.nplanes; p++) W.plane[p] = W.base + plane_off[p];
+    W.type = li.dev_type;
+    W.src_type = src_type;
+    W.k = k; W.n = n; W.n_stack = n_stack;
+    W.bytes = 0;
+    for (int p = 0; p < li.nplanes; p++) W.bytes += W.stack_stride[p];  // per expert
+    c->stats.weight_bytes += (li.dev_type == LGH_TYPE_F32 ? (uint64_t)n * k * 4 : per_expert_src) * n_stack;
+  } else if (W.src_type != src_type || W.k != k || W.n != n || W.n_stack != n_stack) {
+    return fail(c, LGH_SHAPE_MISMATCH, "expert tensors of one stack differ in type or shape");
+  }
+  const uint32_t e0 = slot < 0 ? 0 : (uint32_t)slot;
+  if (li.dev_type == src_type && li.nplanes == 1) {  // native layout: straight copy
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy((void*)(W.plane[0] + (uint64_t)e0 * W.stack_stride[0]), host, nbytes, hipMemcpyHostToDevice));
+    return LGH_OK;
+  }
+  void* raw = nullptr;
+  HIP_TRY(c, LGH_ALLOCATION_FAILED, hipMalloc(&raw, nbytes));
+  hipError_t e = hipMemcpy(raw, host, nbytes, hipMemcpyHostToDevice);
+  for (uint32_t i = 0; i < n_in_payload && e == hipSuccess; i++) {
+    const uint8_t* src = (const uint8_t*)raw + (uint64_t)i * per_expert_src;
+    if (li.dev_type == LGH_TYPE_F32) {
+      e = dequant_launch(src_type, src, (float*)(W.plane[0] + (uint64_t)(e0 + i) * W.stack_stride[0]), (uint64_t)n * k, c->stream);
+    } else {
+      uint64_t po[4];
+      for (int p = 0; p < 4; p++) po[p] = (uint64_t)(W.plane[p] - W.base) + (uint64_t)(e0 + i) * W.stack_stride[p];
+      e = repack_launch(src_type, src, W.base, po, blocks_per_expert, c->stream);
+    }
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(raw);
+  if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("weight re-layout: ") + hipGetErrorString(e));
+  return LGH_OK;
+}
+
+// 1-D tensors (norm weights, biases) and the f32 router matrix: always f32 on device
+int upload_f32(lgh_ctx* c, float** dst, int src_type, uint64_t n, const void* host, size_t nbytes) {
+  const uint32_t sbe = blk_elems(src_type), sbb = blk_bytes(src_type);
+  if (!sbe || n % sbe || nbytes != n / sbe * sbb) return fail(c, LGH_SHAPE_MISMATCH, "vector byte size does not match its shape");
+  if (!*dst) {
+    int rc = dev_alloc(c, (void**)dst, n * 4);
+    if (rc) return rc;
+    c->stats.weight_bytes += n * 4;
+  }
+  if (src_type == LGH_TYPE_F32) {
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(*dst, host, nbytes, hipMemcpyHostToDevice));
+    return LGH_OK;
+  }
+  void* raw = nullptr;
+  HIP_TRY(c, LGH_ALLOCATION_FAILED, hipMalloc(&raw, nbytes));
+  hipError_t e = hipMemcpy(raw, host, nbytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = dequant_launch(src_type, (const uint8_t*)raw, *dst, n, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(raw);
+  if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("vector upload: ") + hipGetErrorString(e));
+  return LGH_OK;
+}
+
+int drain_prof(lgh_ctx* c) {
+  if (c->prof.empty()) return LGH_OK;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  for (auto& r : c->prof) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->stats.k_time_us[r.cls] += (double)ms * 1000.0;
+      c->stats.k_launches[r.cls] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  c->prof.clear();
+  return LGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused mat-vec launch assembly
+// ------------------------------------------------------------------------------------------------
+int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k) {
+  MvLaunch L;
+  std::memset(&L, 0, sizeof(L));
+  L.nseg = nseg;
+  L.k = k;
+  L.do_norm = norm_w != nullptr;
+  L.eps = c->d.norm_eps;
+  L.norm_w = norm_w;
+  L.pos = c->state + ST_POS;
+  L.rope_cs = c->rope_cs;
+  uint32_t wg = 0, threads = 0;
+  uint64_t alg = 0;
+  for (int s = 0; s < nseg; s++) {
+    const SegSpec& sp = specs[s];
+    const DevWeight& W0 = *sp.W[0];
+    MvPlan plan;
+    if (mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan) != hipSuccess)
+      return fail(c, LGH_UNSUPPORTED, "no fused mat-vec plan for type " + std::to_string(W0.type) + " k=" + std::to_string(W0.k));
+    MvSeg& S = L.seg[s];
+    S.type = W0.type;
+    S.epi = sp.epi;
+    S.n_rows = W0.n;
+    S.nblk = W0.k / layout_for(W0.src_type).belems;
+    S.units = plan.units; S.T = plan.T; S.G = plan.G;
+    S.rows_per_wg = plan.rows_per_wg;
+    S.wg_begin = wg;
+    S.npass = sp.npass;
+    for (int p = 0; p < sp.npass; p++) {
+      const DevWeight& W = *sp.W[p];
+      if (W.type != W0.type || W.k != W0.k || W.n != W0.n) return fail(c, LGH_SHAPE_MISMATCH, "passes of one segment differ in type/shape");
+      for (int i = 0; i < 4; i++) { S.pass[p].plane[i] = W.plane[i]; S.pass[p].sel_stride[i] = W.stack_stride[i]; }
+      S.pass[p].x = sp.x[p];
+      S.pass[p].sel = sp.sel[p];
+      alg += W.bytes;
+    }
+    S.out = sp.out; S.out2 = sp.out2; S.resid = sp.resid; S.bias = sp.bias; S.moe_w = sp.moe_w;
+    S.head_dim = c->d.head_dim;
+    S.max_seq = c->d.max_seq_len;
+    wg += plan.n_wg;
+    if (plan.threads > threads) threads = plan.threads;
+  }
+  alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
+  return run_k(c, cls, alg, [&] { return mv_launch(L, wg, threads, c->stream); });
+}
+
+// one Linear with optional norm prologue / residual epilogue, any device type
+int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* out, const float* norm_w,
+                      const float* resid, const float* bias) {
+  if (fused_type(W.type)) {
+    SegSpec sp;
+    sp.W[0] = &W; sp.x[0] = x;
+    sp.epi = resid ? EPI_RESID : EPI_STORE;
+    sp.out = out; sp.resid = resid; sp.bias = bias;
+    return launch_mv(c, cls, &sp, 1, norm_w, W.k);
+  }
+  if (bias) return fail(c, LGH_UNSUPPORTED, "bias on a non-quantized linear layer is not supported");
+  return run_k(c, cls, (uint64_t)W.n * W.k * 4, [&] {
+    return f32_matvec_launch((const float*)W.plane[0], x, out, W.k, W.n, norm_w, c->d.norm_eps, resid, c->stream);
+  });
+}
+
+// ------------------------------------------------------------------------------------------------
+// one transformer layer (TransformerLayer::forward serial-residual branch, layers.rs:1187-1244)
+// ------------------------------------------------------------------------------------------------
+static int layer_forward(lgh_ctx* c, uint32_t li) {
+  LayerW& Lw = c->layers[li];
+  const lgh_model_desc& d = c->d;
+  const uint32_t H = d.hidden_size;
+  int rc;
+  // ---- attention: norm -> q,k,v -> rope -> cache write (layers.rs:438-600)
+  const bool fused_qkv = fused_type(Lw.wq.type) && fused_type(Lw.wk.type) && fused_type(Lw.wv.type) && !d.use_neox_rope;
+  if (fused_qkv) {
+    SegSpec sp[3];
+    sp[0].W[0] = &Lw.wq; sp[0].x[0] = c->hidden; sp[0].epi = EPI_ROPE_Q; sp[0].out = c->q; sp[0].bias = Lw.bq;
+    sp[1].W[0] = &Lw.wk; sp[1].x[0] = c->hidden; sp[1].epi = EPI_ROPE_K; sp[1].out = Lw.kcache; sp[1].bias = Lw.bk;
+    sp[2].W[0] = &Lw.wv; sp[2].x[0] = c->hidden; sp[2].epi = EPI_V_CACHE; sp[2].out = Lw.vcache; sp[2].bias = Lw.bv;
+    if ((rc = launch_mv(c, LGH_K_QKV, sp, 3, Lw.attn_norm, H))) return rc;
+  } else {
+    float* kt = c->kv_tmp;
+    float* vt = c->kv_tmp + (size_t)d.num_kv_heads * d.head_dim;
+    if ((rc = linear_any(c, LGH_K_QKV, Lw.wq, c->hidden, c->q, Lw.attn_norm, nullptr, Lw.bq))) return rc;
+    if ((rc = linear_any(c, LGH_K_QKV, Lw.wk, c->hidden, kt, Lw.attn_norm, nullptr, Lw.bk))) return rc;
+    if ((rc = linear_any(c, LGH_K_QKV, Lw.wv, c->hidden, vt, Lw.attn_norm, nullptr, Lw.bv))) return rc;
+    if ((rc = run_k(c, LGH_K_MISC, 0, [&] {
+           return rope_launch(c->q, kt, d.num_heads, d.num_kv_heads, d.head_dim, c->state + ST_POS, c->rope_cs, (int)d.use_neox_rope, c->stream);
+         })))
+      return rc;
+    if ((rc = run_k(c, LGH_K_MISC, 0, [&] {
+           return kv_store_launch(kt, vt, Lw.kcache, Lw.vcache, d.num_kv_heads, d.head_dim, d.max_seq_len, c->state + ST_POS, c->stream);
+         })))
+      return rc;
+  }
+  // ---- attention_cached (ops.rs:1479-1537)
+  const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
+  const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
+  if ((rc = run_k(c, LGH_K_ATTN, kv_bytes, [&] {
+         return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
+                            c->state + ST_POS, 0, c->n_splits, c->part_ml, c->part_acc, c->stream);
+       })))
+    return rc;
+  if ((rc = run_k(c, LGH_K_ATTN_COMBINE, 0, [&] {
+         return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out, c->stream);
+       })))
+    return rc;
+  // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
+  if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo))) return rc;
+  // ---- FFN
+  if (!Lw.moe()) {
+    if (fused_type(Lw.gate.type) && Lw.gate.type == Lw.up.type) {  // FeedForward::forward (layers.rs:908-929)
+      SegSpec sp;
+      sp.npass = 2;
+      sp.W[0] = &Lw.gate; sp.W[1] = &Lw.up;
+      sp.x[0] = sp.x[1] = c->hidden;
+      sp.epi = EPI_SWIGLU;
+      sp.out = c->act;
+      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
+    } else {
+      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.gate, c->hidden, c->act, Lw.ffn_norm, nullptr, nullptr))) return rc;
+      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.up, c->hidden, c->act2, Lw.ffn_norm, nullptr, nullptr))) return rc;
+      if ((rc = run_k(c, LGH_K_MISC, 0, [&] { return silu_mul_launch(c->act, c->act2, c->act, Lw.gate.n, c->stream); }))) return rc;
+    }
+    return linear_any(c, LGH_K_DOWN, Lw.down, c->act, c->hidden, nullptr, c->hidden, nullptr);
+  }
+  // ---- MoE (moe.rs:321-413): router + top-k on device, experts selected by device-side index
+  const uint32_t topk = d.num_experts_per_token;
+  if ((rc = run_k(c, LGH_K_ROUTER, (uint64_t)d.num_experts * H * 4, [&] {
+         return moe_router_launch(c->hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, d.num_experts, topk, c->moe_sel, c->moe_w, c->stream);
+       })))
+    return rc;
+  if (!fused_type(Lw.gate_exps.type) || Lw.gate_exps.type != Lw.up_exps.type || !fused_type(Lw.down_exps.type) || topk > 2)
+    return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 2");
+  {
+    SegSpec sp;
+    sp.npass = (int)(2 * topk);
+    for (uint32_t s = 0; s < topk; s++) {
+      sp.W[2 * s] = &Lw.gate_exps; sp.W[2 * s + 1] = &Lw.up_exps;
+      sp.x[2 * s] = sp.x[2 * s + 1] = c->hidden;
+      sp.sel[2 * s] = sp.sel[2 * s + 1] = c->moe_sel + s;
+    }
+    sp.epi = EPI_MOE_SWIGLU;
+    sp.out = c->act; sp.out2 = c->act2;
+    if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
+  }
+  {
+    SegSpec sp;
+    sp.npass = (int)topk;
+    for (uint32_t s = 0; s < topk; s++) {
+      sp.W[s] = &Lw.down_exps;
+      sp.x[s] = s == 0 ? c->act : c->act2;
+      sp.sel[s] = c->moe_sel + s;
+    }
+    sp.epi = EPI_MOE_DOWN;
+    sp.out = c->hidden; sp.resid = c->hidden; sp.moe_w = c->moe_w;
+    if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
+  }
+  return LGH_OK;
+}
+
+// Everything one token needs, in stream order.  Used eagerly and under graph capture.
+static int enqueue_token(lgh_ctx* c, int mode) {
+  const lgh_model_desc& d = c->d;
+  int rc;
+  if (c->first) {
+    if ((rc = run_k(c, LGH_K_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
+           return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, c->stream);
+         })))
+      return rc;
+  } else {
+    if ((rc = run_k(c, LGH_K_MISC, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
+  }
+  for (uint32_t li = c->l0; li < c->l1; li++)
+    if ((rc = layer_forward(c, li))) return rc;
+  if (c->last && mode != MODE_PREFILL) {
+    // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
+    if ((rc = linear_any(c, LGH_K_OUTPUT, c->output, c->hidden, c->logits, c->output_norm, nullptr, nullptr))) return rc;
+    if (mode == MODE_GREEDY) {
+      if ((rc = run_k(c, LGH_K_ARGMAX, (uint64_t)d.vocab_size * 4, [&] {
+             return argmax_launch(c->logits, d.vocab_size, c->amax_v, c->amax_i, c->state, c->tok_log, c->stream);
+           })))
+        return rc;
+    }
+  }
+  return LGH_OK;
+}
+
+static int ensure_graph(lgh_ctx* c, int mode) {
+  if (c->graph[mode]) return LGH_OK;
+  hipGraph_t g = nullptr;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_token(c, mode);
+  hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  size_t n_nodes = 0;
+  (void)hipGraphGetNodes(g, nullptr, &n_nodes);
+  if (mode == MODE_GREEDY || c->graph_nodes == 0) c->graph_nodes = n_nodes;
+  e = hipGraphInstantiate(&c->graph[mode], g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+  return LGH_OK;
+}
+
+// run one token in `mode` (token id already in the device state)
+static int step(lgh_ctx* c, int mode) {
+  if (c->pos >= c->d.max_seq_len)  // the reference has no such check: OOB write past the KV capacity
+    return fail(c, LGH_INVALID_ARGUMENT, "position " + std::to_string(c->pos) + " >= max_seq_len " + std::to_string(c->d.max_seq_len));
+  int rc;
+  if (c->profiling || (c->d.flags & LGH_FLAG_NO_GRAPH)) {
+    if ((rc = enqueue_token(c, mode))) return rc;
+    if (c->profiling && (rc = drain_prof(c))) return rc;
+  } else {
+    if ((rc = ensure_graph(c, mode))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode], c->stream));
+  }
+  c->pos += 1;
+  c->stats.tokens_processed += 1;
+  return LGH_OK;
+}
+
+static int bind(const lgh_ctx* c) { return hipSetDevice(c->device) == hipSuccess ? LGH_OK : LGH_NOT_AVAILABLE; }
+
+static int set_token(lgh_ctx* c, uint32_t token) {
+  if (c->first && token >= c->d.vocab_size) return fail(c, LGH_INVALID_ARGUMENT, "token id exceeds vocab size");  // llama.rs:296-302
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_TOKEN), (int)token, 1, c->stream));
+  return LGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int lgh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
+  if (!desc || !out || desc->struct_size != sizeof(lgh_model_desc)) return LGH_INVALID_ARGUMENT;
+  *out = nullptr;
+  const lgh_model_desc& d = *desc;
+  if (!d.hidden_size || !d.num_layers || !d.num_heads || !d.num_kv_heads || !d.head_dim || !d.vocab_size || !d.max_seq_len)
+    return LGH_INVALID_ARGUMENT;
+  if (d.num_heads % d.num_kv_heads || d.head_dim % 2 || d.hidden_size % 32) return LGH_INVALID_ARGUMENT;
+  int ndev = lgh_device_count();
+  if (ndev <= 0 || d.device_id < 0 || d.device_id >= ndev) return LGH_NOT_AVAILABLE;
+  lgh_ctx* c = new lgh_ctx();
+  c->d = d;
+  c->device = d.device_id;
+  c->l0 = d.layer_begin;
+  c->l1 = d.layer_end == 0 ? d.num_layers : d.layer_end;
+  if (c->l0 >= c->l1 || c->l1 > d.num_layers) { delete c; return LGH_INVALID_ARGUMENT; }
+  c->first = c->l0 == 0;
+  c->last = c->l1 == d.num_layers;
+  c->layers.resize(d.num_layers);
+  for (uint32_t i = c->l0; i < c->l1; i++) c->layers[i].owned = true;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return LGH_INITIALIZATION_FAILED;
+  }
+  c->stream = c->own_stream;
+  uint32_t splits = (d.flags >> LGH_FLAG_ATTN_SPLITS_SHIFT) & 0xFFu;
+  if (!splits) {  // aim at ~128 attention workgroups
+    splits = 128 / d.num_kv_heads;
+    if (splits < 1) splits = 1;
+    if (splits > 32) splits = 32;
+  }
+  c->n_splits = splits;
+  *out = c;
+  return LGH_OK;
+}
+
+static bool parse_layer_name(const char* name, uint32_t* layer, std::string* sub) {
+  if (std::strncmp(name, "blk.", 4) != 0) return false;
+  char* end = nullptr;
+  unsigned long l = std::strtoul(name + 4, &end, 10);
+  if (end == name + 4 || *end != '.') return false;
+  *layer = (uint32_t)l;
+  *sub = end + 1;
+  return true;
+}
+
+int lgh_upload_tensor(lgh_ctx* c, const char* name, uint32_t type, const uint64_t ne[4], const void* host, size_t nbytes) {
+  if (!c || !name || !ne || !host) return LGH_INVALID_ARGUMENT;
+  if (bind(c)) return fail(c, LGH_NOT_AVAILABLE, "hipSetDevice failed");
+  if (c->finalized) return fail(c, LGH_INVALID_ARGUMENT, "upload after finalize");
+  const lgh_model_desc& d = c->d;
+  const std::string nm(name);
+  const uint64_t n0 = ne[0], n1 = ne[1] ? ne[1] : 1, n2 = ne[2] ? ne[2] : 1;
+  if (nm == "token_embd.weight") {
+    if (n0 != d.hidden_size || n1 != d.vocab_size) return fail(c, LGH_SHAPE_MISMATCH, "token_embd.weight shape");
+    const uint32_t be = blk_elems((int)type);
+    if (!be || n0 % be || nbytes != n0 / be * blk_bytes((int)type) * n1) return fail(c, LGH_SHAPE_MISMATCH, "token_embd.weight bytes");
+    if (c->first) {
+      int rc = dev_alloc(c, (void**)&c->embd_raw, nbytes);
+      if (rc) return rc;
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(c->embd_raw, host, nbytes, hipMemcpyHostToDevice));
+      c->stats.weight_bytes += nbytes;
+    }
+    c->embd_type = (int)type;
+    c->embd_bytes = nbytes;
+    if (c->last && !c->output.present()) c->embd_host.assign((const uint8_t*)host, (const uint8_t*)host + nbytes);  // tied output?
+    return LGH_OK;
+  }
+  if (nm == "output_norm.weight") {
+    if (!c->last) return LGH_OK;
+    if (n0 != d.hidden_size) return fail(c, LGH_SHAPE_MISMATCH, "output_norm.weight shape");
+    return upload_f32(c, &c->output_norm, (int)type, n0, host, nbytes);
+  }
+  if (nm == "output.weight") {
+    if (!c->last) return LGH_OK;
+    if (n0 != d.hidden_size || n1 != d.vocab_size) return fail(c, LGH_SHAPE_MISMATCH, "output.weight shape");
+    c->embd_host.clear();
+    c->embd_host.shrink_to_fit();
+    return upload_matrix(c, c->output, (int)type, (uint32_t)n0, (uint32_t)n1, 1, -1, host, nbytes);
+  }
+  uint32_t li = 0;
+  std::string sub;
+  if (!parse_layer_name(name, &li, &sub)) return fail(c, LGH_INVALID_ARGUMENT, "unknown tensor name " + nm);
+  if (li >= d.num_layers) return fail(c, LGH_INVALID_ARGUMENT, "layer index out of range: " + nm);
+  LayerW& L = c->layers[li];
+  if (!L.owned) return LGH_OK;  // another pipeline stage owns it
+  const uint32_t H = d.hidden_size, QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim;
+  auto mat = [&](DevWeight& W, uint64_t k, uint64_t n) -> int {
+    if (n0 != k || n1 != n) return fail(c, LGH_SHAPE_MISMATCH, nm + ": expected [" + std::to_string(k) + "," + std::to_string(n) + "]");
+    return upload_matrix(c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, host, nbytes);
+  };
+  auto vec = [&](float** dst, uint64_t n) -> int {
+    if (n0 * n1 != n) return fail(c, LGH_SHAPE_MISMATCH, nm + ": expected " + std::to_string(n) + " elements");
+    return upload_f32(c, dst, (int)type, n, host, nbytes);
+  };
+  const uint32_t EI = d.expert_intermediate_size ? d.expert_intermediate_size : d.intermediate_size;
+  if (sub == "attn_norm.weight") return vec(&L.attn_norm, H);
+  if (sub == "ffn_norm.weight") return vec(&L.ffn_norm, H);
+  if (sub == "attn_q.weight") return mat(L.wq, H, QD);
+  if (sub == "attn_k.weight") return mat(L.wk, H, KD);
+  if (sub == "attn_v.weight") return mat(L.wv, H, KD);
+  if (sub == "attn_output.weight") return mat(L.wo, QD, H);
+  if (sub == "attn_q.bias") return vec(&L.bq, QD);
+  if (sub == "attn_k.bias") return vec(&L.bk, KD);
+  if (sub == "attn_v.bias") return vec(&L.bv, KD);
+  if (sub == "attn_output.bias") return vec(&L.bo, H);
+  if (sub == "ffn_gate.weight") return mat(L.gate, H, d.intermediate_size);
+  if (sub == "ffn_up.weight") return mat(L.up, H, d.intermediate_size);
+  if (sub == "ffn_down.weight") return mat(L.down, d.intermediate_size, H);
+  if (sub == "ffn_gate_inp.weight") {  // router [hidden, n_experts], must be F32 (moe.rs:132-135)
+    if (type != LGH_TYPE_F32) return fail(c, LGH_DTYPE_MISMATCH, "router weight must be F32");
+    return vec(&L.router, (uint64_t)H * d.num_experts);
+  }
+  // expert stacks: 3-D [in, out, n_expert], expert outermost (loader.rs:1256-1303)
+  auto stack = [&](DevWeight& W, uint64_t k, uint64_t n) -> int {
+    if (n0 != k || n1 != n || n2 != d.num_experts) return fail(c, LGH_SHAPE_MISMATCH, nm + ": bad expert stack shape");
+    return upload_matrix(c, W, (int)type, (uint32_t)k, (uint32_t)n, d.num_experts, -1, host, nbytes);
+  };
+  if (sub == "ffn_gate_exps.weight") return stack(L.gate_exps, H, EI);
+  if (sub == "ffn_up_exps.weight") return stack(L.up_exps, H, EI);
+  if (sub == "ffn_down_exps.weight") return stack(L.down_exps, EI, H);
+  // per-expert tensors as the loader renames them: ffn_gate.{e}.weight (loader.rs:1171-1173)
+  auto one_expert = [&](const char* prefix, DevWeight& W, uint64_t k, uint64_t n) -> int {
+    size_t pl = std::strlen(prefix);
+    if (sub.compare(0, pl, prefix) != 0) return -1;
+    char* end = nullptr;
+    unsigned long e = std::strtoul(sub.c_str() + pl, &end, 10);
+    if (end == sub.c_str() + pl || std::strcmp(end, ".weight") != 0) return -1;
+    if (e >= d.num_experts) return fail(c, LGH_INVALID_ARGUMENT, nm + ": expert index out of range");
+    if (n0 != k || n1 != n) return fail(c, LGH_SHAPE_MISMATCH, nm + ": bad expert shape");
+    return upload_matrix(c, W, (int)type, (uint32_t)k, (uint32_t)n, d.num_experts, (int)e, host, nbytes);
+  };
+  int r;
+  if ((r = one_expert("ffn_gate.", L.gate_exps, H, EI)) >= 0) return r;
+  if ((r = one_expert("ffn_up.", L.up_exps, H, EI)) >= 0) return r;
+  if ((r = one_expert("ffn_down.", L.down_exps, EI, H)) >= 0) return r;
+  return fail(c, LGH_INVALID_ARGUMENT, "unknown tensor name " + nm);
+}
+
+int lgh_finalize(lgh_ctx* c) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (bind(c)) return fail(c, LGH_NOT_AVAILABLE, "hipSetDevice failed");
+  if (c->finalized) return LGH_OK;
+  const lgh_model_desc& d = c->d;
+  int rc;
+  if (c->first && !c->embd_raw) return fail(c, LGH_INITIALIZATION_FAILED, "missing token_embd.weight");
+  if (c->last) {
+    if (!c->output_norm) return fail(c, LGH_INITIALIZATION_FAILED, "missing output_norm.weight");
+    if (!c->output.present()) {  // tied output projection (loader.rs:348-355)
+      if (c->embd_host.empty()) return fail(c, LGH_INITIALIZATION_FAILED, "missing output.weight and token_embd.weight");
+      if ((rc = upload_matrix(c, c->output, c->embd_type, d.hidden_size, d.vocab_size, 1, -1, c->embd_host.data(), c->embd_host.size()))) return rc;
+    }
+    c->embd_host.clear();
+    c->embd_host.shrink_to_fit();
+  }
+  const size_t kv_elems = (size_t)d.num_kv_heads * d.max_seq_len * d.head_dim;
+  for (uint32_t i = c->l0; i < c->l1; i++) {
+    LayerW& L = c->layers[i];
+    const std::string p = "blk." + std::to_string(i) + ".";
+    if (!L.attn_norm || !L.ffn_norm) return fail(c, LGH_INITIALIZATION_FAILED, "missing norm weights of " + p);
+    if (!L.wq.present() || !L.wk.present() || !L.wv.present() || !L.wo.present()) return fail(c, LGH_INITIALIZATION_FAILED, "missing attention weights of " + p);
+    if (L.moe()) {
+      if (!L.gate_exps.present() || !L.up_exps.present() || !L.down_exps.present()) return fail(c, LGH_INITIALIZATION_FAILED, "missing expert stacks of " + p);
+    } else if (!L.gate.present() || !L.up.present() || !L.down.present()) {
+      return fail(c, LGH_INITIALIZATION_FAILED, "missing FFN weights of " + p);
+    }
+    // per-layer K/V [kv_heads, max_seq, head_dim] f32 (gpu_only.rs:555-572)
+    if ((rc = dev_alloc(c, (void**)&L.kcache, kv_elems * 4))) return rc;
+    if ((rc = dev_alloc(c, (void**)&L.vcache, kv_elems * 4))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(L.kcache, 0, kv_elems * 4, c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(L.vcache, 0, kv_elems * 4, c->stream));
+    c->stats.kv_bytes += 2 * kv_elems * 4;
+  }
+  const uint32_t EI = d.expert_intermediate_size ? d.expert_intermediate_size : d.intermediate_size;
+  const size_t ffn = std::max<size_t>(d.intermediate_size, EI);
+  const size_t G = d.num_heads / d.num_kv_heads;
+  struct { void** p; size_t n; } bufs[] = {
+      {(void**)&c->hidden, (size_t)d.hidden_size * 4},
+      {(void**)&c->xnorm, (size_t)d.hidden_size * 4},
+      {(void**)&c->q, (size_t)d.num_heads * d.head_dim * 4},
+      {(void**)&c->kv_tmp, (size_t)2 * d.num_kv_heads * d.head_dim * 4},
+      {(void**)&c->attn_out, (size_t)d.num_heads * d.head_dim * 4},
+      {(void**)&c->act, ffn * 4},
+      {(void**)&c->act2, ffn * 4},
+      {(void**)&c->logits, (size_t)d.vocab_size * 4},
+      {(void**)&c->part_ml, (size_t)d.num_kv_heads * c->n_splits * G * 2 * 4},
+      {(void**)&c->part_acc, (size_t)d.num_kv_heads * c->n_splits * G * d.head_dim * 4},
+      {(void**)&c->rope_cs, (size_t)d.max_seq_len * d.head_dim * 4},
+      {(void**)&c->moe_w, 8 * 4},
+      {(void**)&c->moe_sel, 8 * 4},
+      {(void**)&c->state, ST_WORDS * 4},
+      {(void**)&c->amax_v, 64 * 4},
+      {(void**)&c->amax_i, 64 * 4},
+      {(void**)&c->tok_log, (size_t)d.max_seq_len * 4},
+  };
+  for (auto& b : bufs) {
+    if ((rc = dev_alloc(c, b.p, b.n))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
+    c->stats.scratch_bytes += b.n;
+  }
+  {
+    // RoPE table in the reference's own arithmetic (ops.rs:1303-1313): libm powf / cosf / sinf on the host
+    const uint32_t half = d.head_dim / 2;
+    std::vector<float> cs((size_t)d.max_seq_len * half * 2);
+    for (uint32_t p = 0; p < d.max_seq_len; p++) {
+      const float position = (float)p / d.rope_freq_scale;
+      for (uint32_t i = 0; i < half; i++) {
+        const float freq = 1.0f / std::pow(d.rope_freq_base, (float)(2 * i) / (float)d.head_dim);
+        const float theta = position * freq;
+        cs[((size_t)p * half + i) * 2] = std::cos(theta);
+        cs[((size_t)p * half + i) * 2 + 1] = std::sin(theta);
+      }
+    }
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(c->rope_cs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  c->finalized = true;
+  c->pos = 0;
+  return LGH_OK;
+}
+
+void lgh_destroy(lgh_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int m = 0; m < MODE_COUNT; m++)
+    if (c->graph[m]) (void)hipGraphExecDestroy(c->graph[m]);
+  for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+static int check_ready(lgh_ctx* c) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (!c->finalized) return fail(c, LGH_INVALID_ARGUMENT, "context not finalized");
+  if (bind(c)) return fail(c, LGH_NOT_AVAILABLE, "hipSetDevice failed");
+  return LGH_OK;
+}
+
+int lgh_forward(lgh_ctx* c, uint32_t token, float* logits_out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!logits_out) return fail(c, LGH_INVALID_ARGUMENT, "logits_out is NULL");
+  if (!c->first || !c->last) return fail(c, LGH_INVALID_ARGUMENT, "lgh_forward needs a single-stage context; use lgh_stage_forward");
+  if ((rc = set_token(c, token))) return rc;
+  if ((rc = step(c, MODE_FORWARD))) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
+int lgh_prefill_token(lgh_ctx* c, uint32_t token) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!c->first || !c->last) return fail(c, LGH_INVALID_ARGUMENT, "lgh_prefill_token needs a single-stage context");
+  if ((rc = set_token(c, token))) return rc;
+  return step(c, MODE_PREFILL);
+}
+
+int lgh_prefill_batch(lgh_ctx* c, const uint32_t* tokens, size_t n) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (n && !tokens) return fail(c, LGH_INVALID_ARGUMENT, "tokens is NULL");
+  for (size_t i = 0; i < n; i++)
+    if ((rc = lgh_prefill_token(c, tokens[i]))) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
+void lgh_reset(lgh_ctx* c) {
+  if (!c || !c->finalized) return;
+  if (bind(c)) return;
+  (void)hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), 0, 1, c->stream);
+  c->pos = 0;
+}
+
+size_t lgh_position(const lgh_ctx* c) { return c ? c->pos : 0; }
+
+int lgh_forward_argmax(lgh_ctx* c, uint32_t token, uint32_t* next_token) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!next_token) return fail(c, LGH_INVALID_ARGUMENT, "next_token is NULL");
+  if (!c->first || !c->last) return fail(c, LGH_INVALID_ARGUMENT, "needs a single-stage context");
+  if ((rc = set_token(c, token))) return rc;
+  if ((rc = step(c, MODE_GREEDY))) return rc;
+  int tok = 0;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(&tok, c->state + ST_ARGMAX, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  *next_token = (uint32_t)tok;
+  return LGH_OK;
+}
+
+int lgh_decode_greedy(lgh_ctx* c, uint32_t first_token, size_t n_steps, uint32_t* tokens_out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (n_steps && !tokens_out) return fail(c, LGH_INVALID_ARGUMENT, "tokens_out is NULL");
+  if (!c->first || !c->last) return fail(c, LGH_INVALID_ARGUMENT, "needs a single-stage context");
+  if (c->pos + n_steps > c->d.max_seq_len) return fail(c, LGH_INVALID_ARGUMENT, "decode would exceed max_seq_len");
+  if ((rc = set_token(c, first_token))) return rc;
+  // argmax_stage2 writes each token into state[TOKEN] (the feedback) and into tok_log[position]
+  const size_t pos0 = c->pos;
+  for (size_t i = 0; i < n_steps; i++)
+    if ((rc = step(c, MODE_GREEDY))) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(tokens_out, c->tok_log + pos0, n_steps * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
+const char* lgh_last_error(const lgh_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
+  if (!c || !out) return LGH_INVALID_ARGUMENT;
+  c->stats.graph_nodes = c->graph_nodes;
+  // algorithmic bytes of one decode step at the current position
+  uint64_t b = 0;
+  const lgh_model_desc& d = c->d;
+  if (c->finalized) {
+    if (c->first) b += (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type);
+    for (uint32_t i = c->l0; i < c->l1; i++) {
+      const LayerW& L = c->layers[i];
+      b += L.wq.bytes + L.wk.bytes + L.wv.bytes + L.wo.bytes;
+      if (L.moe()) b += (uint64_t)d.num_experts_per_token * (L.gate_exps.bytes + L.up_exps.bytes + L.down_exps.bytes) + (uint64_t)d.num_experts * d.hidden_size * 4;
+      else b += L.gate.bytes + L.up.bytes + L.down.bytes;
+      b += (uint64_t)2 * d.hidden_size * 4;                                       // norm weights
+      b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;          // KV read (kv_len = pos+1)
+      b += (uint64_t)2 * d.num_kv_heads * d.head_dim * 4;                         // KV write
+    }
+    if (c->last) b += c->output.bytes + (uint64_t)d.hidden_size * 4 + (uint64_t)d.vocab_size * 4;
+  }
+  c->stats.step_alg_bytes = b;
+  *out = c->stats;
+  return LGH_OK;
+}
+
+int lgh_set_profiling(lgh_ctx* c, int on) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  c->profiling = on != 0;
+  if (on) {
+    std::memset(c->stats.k_launches, 0, sizeof(c->stats.k_launches));
+    std::memset(c->stats.k_time_us, 0, sizeof(c->stats.k_time_us));
+    std::memset(c->stats.k_alg_bytes, 0, sizeof(c->stats.k_alg_bytes));
+  }
+  return LGH_OK;
+}
+
+int lgh_set_stream(lgh_ctx* c, void* s) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (bind(c)) return LGH_NOT_AVAILABLE;
+  (void)hipStreamSynchronize(c->stream);
+  hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
+  if (ns != c->stream) {
+    for (int m = 0; m < MODE_COUNT; m++)
+      if (c->graph[m]) { (void)hipGraphExecDestroy(c->graph[m]); c->graph[m] = nullptr; }
+  }
+  c->stream = ns;
+  return LGH_OK;
+}
+
+void* lgh_get_stream(lgh_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lgh_synchronize(lgh_ctx* c) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (bind(c)) return LGH_NOT_AVAILABLE;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
+int lgh_read_hidden(lgh_ctx* c, float* out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(out, c->hidden, (size_t)c->d.hidden_size * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
+int lgh_stage_hidden_buffer(lgh_ctx* c, void** p) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!p) return LGH_INVALID_ARGUMENT;
+  *p = c->hidden;
+  return LGH_OK;
+}
+
+int lgh_stage_forward(lgh_ctx* c, uint32_t token, int want_logits, float* logits_out, uint32_t* next_token) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (c->first && (rc = set_token(c, token))) return rc;
+  int mode = MODE_PREFILL;
+  if (c->last && want_logits) mode = next_token ? MODE_GREEDY : MODE_FORWARD;
+  if ((rc = step(c, mode))) return rc;
+  if (c->last && want_logits) {
+    int tok = 0;
+    if (logits_out) HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+    if (next_token) HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(&tok, c->state + ST_ARGMAX, 4, hipMemcpyDeviceToHost, c->stream));
+    if (logits_out || next_token) HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+    if (next_token) *next_token = (uint32_t)tok;
+  }
+  return LGH_OK;
+}
+
+}  // extern "C"

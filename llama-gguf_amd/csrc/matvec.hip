@@ -1,0 +1,512 @@
+// matvec.hip — dequant-fused quantized mat-vec for single-token decode on gfx950.
+//
+// Replaces the reference's `vec_mat_q*` CUDA kernels (src/backend/cuda/kernels.rs:443-729: one thread
+// per output column walking K serially over blocks at stride n*144 — uncoalesced) and their call
+// sites `linear_gpu` / `dense_ffn_gpu_forward` / `moe_gpu_forward`
+// (src/backend/cuda/gpu_only.rs:209-329, 1605-1651, 1765-2011).  Arithmetic follows the CPU backend's
+// fused dots (src/backend/cpu/simd.rs:931-1146): x stays f32 (no activation quantization); per
+// 32-group `sum(q*x)` and `sum(x)` are accumulated and the f16 scales applied once per group.
+//
+// Design for CDNA4 (HBM-bound, 3.5 flop/B):
+//   * weights are the only streamed operand: each lane issues 16-byte non-temporal loads straight to
+//     VGPRs (no LDS round trip), B rows deep, so a wave keeps B KiB in flight;
+//   * a lane owns a fixed 32/64-element slice of K ("unit") for the whole kernel, so its slice of x
+//     (and the per-16 sums of x used by the min/offset terms) live in registers and cost nothing per row;
+//   * a row of K elements is covered by T = ceil(units/64) waves of one workgroup (k-slices); partial
+//     sums meet in LDS once, at the end of the workgroup;
+//   * RMSNorm is a prologue (every workgroup re-derives the 1/rms from the L2-resident x), and
+//     residual add / SwiGLU / RoPE + KV-cache write / MoE expert mixing are epilogues, so a dense
+//     layer is 5 launches instead of the reference's ~20.
+#include "device_utils.h"
+
+namespace lgh {
+
+enum : uint32_t { M_Q4K = 1, M_Q5K = 2, M_Q6K = 4, M_Q80 = 8, M_Q40 = 16, M_ALL = 31 };
+
+__device__ __forceinline__ void load_run16(float* dst, const float* x, const float* nw, float inv, bool do_norm) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    if (do_norm) {
+      f32x4 w = *reinterpret_cast<const f32x4*>(nw + 4 * i);
+      // (x * inv_rms) * w : two roundings, as simd.rs:891-892
+      v = (v * inv) * w;
+    }
+    dst[4 * i + 0] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ float sum16(const float* v) {
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s += v[i];
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------ Q4_K
+// unit u of a row: block u>>3, nibble pair p=(u>>1)&3, half h=u&1.  The lane's 16 qs bytes
+// qs[32p+16h .. +16) hold elements 64p+16h+j (low nibbles, sub-block 2p) and 64p+32+16h+j (high
+// nibbles, sub-block 2p+1)   — layout of dequant.rs:232-255.
+struct FmtQ4K {
+  static constexpr int B = 8;
+  static constexpr uint32_t UNIT = 32;
+  struct X { float lo[16], hi[16]; float slo, shi; uint32_t sh; uint32_t upper; };
+  struct Raw { u32x4 hd, qs; };
+
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+    uint32_t p = (u >> 1) & 3;
+    uint32_t e0 = (u >> 3) * 256 + p * 64 + (u & 1) * 16;
+    load_run16(X_.lo, x + e0, nw + e0, inv, nrm);
+    load_run16(X_.hi, x + e0 + 32, nw + e0 + 32, inv, nrm);
+    X_.slo = sum16(X_.lo);
+    X_.shi = sum16(X_.hi);
+    X_.sh = (p & 1) * 16;
+    X_.upper = p >> 1;
+  }
+  static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
+    const uint8_t* b = pl[0] + ((size_t)row * nblk + (u >> 3)) * 144;
+    r.hd = ldg_nt128(b);
+    r.qs = ldg_nt128(b + 16 + (u & 7) * 16);
+  }
+  // 6-bit (scale,min) of sub-blocks 2p and 2p+1 (dequant.rs:210-223), two at a time in 16-bit lanes
+  static __device__ __forceinline__ void scales(const u32x4& hd, const X& X_, float& sc_lo, float& sc_hi, float& m_lo,
+                                                float& m_hi) {
+    uint32_t a = (hd.y >> X_.sh) & 0xFFFFu, b = (hd.z >> X_.sh) & 0xFFFFu, c = (hd.w >> X_.sh) & 0xFFFFu;
+    uint32_t sc_l = a & 0x3F3Fu, m_l = b & 0x3F3Fu;
+    uint32_t sc_u = (c & 0x0F0Fu) | ((a >> 2) & 0x3030u);
+    uint32_t m_u = ((c >> 4) & 0x0F0Fu) | ((b >> 2) & 0x3030u);
+    uint32_t sc2 = X_.upper ? sc_u : sc_l, m2 = X_.upper ? m_u : m_l;
+    sc_lo = ub0(sc2); sc_hi = ub1(sc2);
+    m_lo = ub0(m2); m_hi = ub1(m2);
+  }
+  static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
+    float alo = 0.0f, ahi = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t v = r.qs[w];
+      alo = fma4(v & 0x0F0F0F0Fu, X_.lo + 4 * w, alo);
+      ahi = fma4((v >> 4) & 0x0F0F0F0Fu, X_.hi + 4 * w, ahi);
+    }
+    float sc_lo, sc_hi, m_lo, m_hi;
+    scales(r.hd, X_, sc_lo, sc_hi, m_lo, m_hi);
+    float d = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
+    return d * __builtin_fmaf(sc_lo, alo, sc_hi * ahi) - dmin * __builtin_fmaf(m_lo, X_.slo, m_hi * X_.shi);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ Q5_K
+// as Q4_K plus qh[32]: bit 2p of qh[16h+j] is the 5th bit of the low-nibble element, bit 2p+1 of the
+// high-nibble element (dequant.rs:287-315).
+struct FmtQ5K {
+  static constexpr int B = 6;
+  static constexpr uint32_t UNIT = 32;
+  struct X { float lo[16], hi[16]; float slo, shi; uint32_t sh; uint32_t upper; uint32_t qsh; };
+  struct Raw { u32x4 hd, qh, qs; };
+
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+    uint32_t p = (u >> 1) & 3;
+    uint32_t e0 = (u >> 3) * 256 + p * 64 + (u & 1) * 16;
+    load_run16(X_.lo, x + e0, nw + e0, inv, nrm);
+    load_run16(X_.hi, x + e0 + 32, nw + e0 + 32, inv, nrm);
+    X_.slo = sum16(X_.lo);
+    X_.shi = sum16(X_.hi);
+    X_.sh = (p & 1) * 16;
+    X_.upper = p >> 1;
+    X_.qsh = 2 * p;
+  }
+  static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
+    const uint8_t* b = pl[0] + ((size_t)row * nblk + (u >> 3)) * 176;
+    r.hd = ldg_nt128(b);
+    r.qh = ldg_nt128(b + 16 + (u & 1) * 16);
+    r.qs = ldg_nt128(b + 48 + (u & 7) * 16);
+  }
+  static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
+    float alo = 0.0f, ahi = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t v = r.qs[w], t = r.qh[w] >> X_.qsh;
+      uint32_t qlo = (v & 0x0F0F0F0Fu) | ((t << 4) & 0x10101010u);
+      uint32_t qhi = ((v >> 4) & 0x0F0F0F0Fu) | ((t << 3) & 0x10101010u);
+      alo = fma4(qlo, X_.lo + 4 * w, alo);
+      ahi = fma4(qhi, X_.hi + 4 * w, ahi);
+    }
+    float sc_lo, sc_hi, m_lo, m_hi;
+    FmtQ4K::X sx;  // reuse the Q4_K scale unpack (same 12-byte packing)
+    sx.sh = X_.sh; sx.upper = X_.upper;
+    FmtQ4K::scales(r.hd, sx, sc_lo, sc_hi, m_lo, m_hi);
+    float d = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
+    return d * __builtin_fmaf(sc_lo, alo, sc_hi * ahi) - dmin * __builtin_fmaf(m_lo, X_.slo, m_hi * X_.shi);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ Q6_K
+// planes: ql[128], qh[64], scales[16] (i8), d per block.  unit u: block u>>2, half n=(u>>1)&1,
+// column group c=u&1 (l = 16c..16c+15).  Quarter t of the half (elements 128n+32t+l) takes its low
+// nibble from ql[64n+32(t&1)+l] (high nibble for t>=2) and bits 2t..2t+1 of qh[32n+l]; scale index
+// 8n+c+2t  (dequant.rs:321-356).  q-32 is folded in as  sum(q*x) - 32*sum(x).
+struct FmtQ6K {
+  static constexpr int B = 4;
+  static constexpr uint32_t UNIT = 64;
+  struct X { float q[4][16]; float s[4]; uint32_t shc; };
+  struct Raw { u32x4 qa, qb, qh; u32x2 sc; uint32_t d; };
+
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+    uint32_t e0 = (u >> 2) * 256 + ((u >> 1) & 1) * 128 + (u & 1) * 16;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      load_run16(X_.q[t], x + e0 + 32 * t, nw + e0 + 32 * t, inv, nrm);
+      X_.s[t] = sum16(X_.q[t]);
+    }
+    X_.shc = (u & 1) * 8;
+  }
+  static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
+    size_t blk = (size_t)row * nblk + (u >> 2);
+    uint32_t n = (u >> 1) & 1, c = u & 1;
+    const uint8_t* ql = pl[0] + blk * 128 + n * 64 + c * 16;
+    r.qa = ldg_nt128(ql);
+    r.qb = ldg_nt128(ql + 32);
+    r.qh = ldg_nt128(pl[1] + blk * 64 + n * 32 + c * 16);
+    r.sc = ldg_nt64(pl[2] + blk * 16 + n * 8);
+    r.d = ldg_nt16(pl[3] + blk * 2);
+  }
+  static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t a = r.qa[w], b = r.qb[w], h = r.qh[w];
+      uint32_t v0 = (a & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
+      uint32_t v1 = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
+      uint32_t v2 = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
+      uint32_t v3 = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
+      a0 = fma4(v0, X_.q[0] + 4 * w, a0);
+      a1 = fma4(v1, X_.q[1] + 4 * w, a1);
+      a2 = fma4(v2, X_.q[2] + 4 * w, a2);
+      a3 = fma4(v3, X_.q[3] + 4 * w, a3);
+    }
+    uint64_t sv = (((uint64_t)r.sc.y << 32) | r.sc.x) >> X_.shc;
+    float s0 = (float)(int)(int8_t)(sv), s1 = (float)(int)(int8_t)(sv >> 16);
+    float s2 = (float)(int)(int8_t)(sv >> 32), s3 = (float)(int)(int8_t)(sv >> 48);
+    float t = s0 * __builtin_fmaf(-32.0f, X_.s[0], a0);
+    t = __builtin_fmaf(s1, __builtin_fmaf(-32.0f, X_.s[1], a1), t);
+    t = __builtin_fmaf(s2, __builtin_fmaf(-32.0f, X_.s[2], a2), t);
+    t = __builtin_fmaf(s3, __builtin_fmaf(-32.0f, X_.s[3], a3), t);
+    return h2f(r.d) * t;
+  }
+};
+
+// ------------------------------------------------------------------------------------------ Q8_0
+// planes: qs[32] (i8), d per block; unit = one block.  q is read as q+128 (sign bit flipped) so the
+// unsigned byte->f32 convert applies:  sum(q*x) = sum((q^0x80)*x) - 128*sum(x).
+struct FmtQ80 {
+  static constexpr int B = 6;
+  static constexpr uint32_t UNIT = 32;
+  struct X { float v[32]; float s; };
+  struct Raw { u32x4 q0, q1; uint32_t d; };
+
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+    load_run16(X_.v, x + u * 32, nw + u * 32, inv, nrm);
+    load_run16(X_.v + 16, x + u * 32 + 16, nw + u * 32 + 16, inv, nrm);
+    X_.s = sum16(X_.v) + sum16(X_.v + 16);
+  }
+  static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
+    size_t blk = (size_t)row * nblk + u;
+    r.q0 = ldg_nt128(pl[0] + blk * 32);
+    r.q1 = ldg_nt128(pl[0] + blk * 32 + 16);
+    r.d = ldg_nt16(pl[1] + blk * 2);
+  }
+  static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
+    float a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) a = fma4(r.q0[w] ^ 0x80808080u, X_.v + 4 * w, a);
+#pragma unroll
+    for (int w = 0; w < 4; w++) a = fma4(r.q1[w] ^ 0x80808080u, X_.v + 16 + 4 * w, a);
+    return h2f(r.d) * __builtin_fmaf(-128.0f, X_.s, a);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ Q4_0
+// planes: qs[16], d per block; unit = one block: low nibble j -> element j, high nibble -> 16+j
+// (dequant.rs:16-30);  (q-8) folded in as sum(q*x) - 8*sum(x).
+struct FmtQ40 {
+  static constexpr int B = 8;
+  static constexpr uint32_t UNIT = 32;
+  struct X { float lo[16], hi[16]; float s; };
+  struct Raw { u32x4 qs; uint32_t d; };
+
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+    load_run16(X_.lo, x + u * 32, nw + u * 32, inv, nrm);
+    load_run16(X_.hi, x + u * 32 + 16, nw + u * 32 + 16, inv, nrm);
+    X_.s = sum16(X_.lo) + sum16(X_.hi);
+  }
+  static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
+    size_t blk = (size_t)row * nblk + u;
+    r.qs = ldg_nt128(pl[0] + blk * 16);
+    r.d = ldg_nt16(pl[1] + blk * 2);
+  }
+  static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
+    float alo = 0.0f, ahi = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      uint32_t v = r.qs[w];
+      alo = fma4(v & 0x0F0F0F0Fu, X_.lo + 4 * w, alo);
+      ahi = fma4((v >> 4) & 0x0F0F0F0Fu, X_.hi + 4 * w, ahi);
+    }
+    return h2f(r.d) * __builtin_fmaf(-8.0f, X_.s, alo + ahi);
+  }
+};
+
+// ------------------------------------------------------------------------------------------ body
+constexpr int kRedFloats = 4096;
+
+// 1/rms of x over the whole workgroup; identical in every workgroup (fixed reduction order)
+__device__ __forceinline__ float block_inv_rms(const float* x, uint32_t k, float eps, float* wsum) {
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  float ss = 0.0f;
+  for (uint32_t i = tid * 4; i < k; i += nthr * 4) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+    ss = __builtin_fmaf(v.x, v.x, ss);
+    ss = __builtin_fmaf(v.y, v.y, ss);
+    ss = __builtin_fmaf(v.z, v.z, ss);
+    ss = __builtin_fmaf(v.w, v.w, ss);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  float tot = 0.0f;
+  const uint32_t nw = nthr >> 6;
+  for (uint32_t w = 0; w < nw; w++) tot += wsum[w];
+  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
+  float rms = __builtin_sqrtf(tot / (float)k + eps);
+  return 1.0f / rms;
+}
+
+template <class F>
+__device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint32_t wg, float inv, float* red) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave >= S.T * S.G) return;
+  const uint32_t ks = wave % S.T, rg = wave / S.T;
+  const uint32_t u = ks * 64 + lane;
+  const bool uvalid = u < S.units;
+  const uint32_t uc = uvalid ? u : S.units - 1;
+  const uint32_t rpg = S.rows_per_wg / S.G;
+  const uint32_t row0 = wg * S.rows_per_wg + rg * rpg;
+  const bool nrm = L.do_norm != 0;
+  typename F::X X_;
+  for (int p = 0; p < S.npass; p++) {
+    const MvPass& P = S.pass[p];
+    if (p == 0 || P.x != S.pass[p - 1].x) F::load_x(X_, P.x, L.norm_w, inv, nrm, uc);
+    const uint8_t* pl[4];
+    {
+      uint64_t e = P.sel ? (uint64_t)(uint32_t)(*P.sel) : 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) pl[i] = P.plane[i] + e * P.sel_stride[i];
+    }
+    float* rp = red + (size_t)(p * S.T + ks) * S.rows_per_wg + rg * rpg;
+    for (uint32_t i0 = 0; i0 < rpg; i0 += F::B) {
+      typename F::Raw raw[F::B];
+#pragma unroll
+      for (int b = 0; b < F::B; b++) {
+        uint32_t row = row0 + i0 + b;
+        if (i0 + b < rpg && row < S.n_rows) F::load(raw[b], pl, row, S.nblk, uc);
+      }
+#pragma unroll
+      for (int b = 0; b < F::B; b++) {
+        uint32_t row = row0 + i0 + b;
+        if (i0 + b < rpg && row < S.n_rows) {
+          float part = F::dot(raw[b], X_);
+          part = wave_sum(uvalid ? part : 0.0f);
+          if (lane == 0) rp[i0 + b] = part;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
+
+// Per-row epilogue, one thread per row (or per row pair for RoPE)
+__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t rbase = wg * S.rows_per_wg;
+  auto rowval = [&](int p, uint32_t rl) {
+    float v = 0.0f;
+    for (uint32_t ks = 0; ks < S.T; ks++) v += red[(size_t)(p * S.T + ks) * S.rows_per_wg + rl];
+    return v;
+  };
+  if (S.epi == EPI_ROPE_Q || S.epi == EPI_ROPE_K) {
+    uint32_t rl = 2 * t, row = rbase + rl;
+    if (rl >= S.rows_per_wg || row >= S.n_rows) return;
+    float x0 = rowval(0, rl), x1 = rowval(0, rl + 1);
+    if (S.bias) { x0 += S.bias[row]; x1 += S.bias[row + 1]; }
+    const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim, half = d / 2;
+    const uint32_t head = row / d, i = (row % d) / 2;
+    const float c = L.rope_cs[((size_t)pos * half + i) * 2], s = L.rope_cs[((size_t)pos * half + i) * 2 + 1];
+    float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
+    if (S.epi == EPI_ROPE_Q) {
+      S.out[row] = y0;
+      S.out[row + 1] = y1;
+    } else {
+      float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
+      dst[0] = y0;
+      dst[1] = y1;
+    }
+    return;
+  }
+  if (t >= S.rows_per_wg) return;
+  const uint32_t row = rbase + t;
+  if (row >= S.n_rows) return;
+  float v0 = rowval(0, t);
+  if (S.bias) v0 += S.bias[row];
+  switch (S.epi) {
+    case EPI_STORE: S.out[row] = v0; break;
+    case EPI_RESID: S.out[row] = v0 + S.resid[row]; break;
+    case EPI_SWIGLU: {
+      float up = rowval(1, t);
+      S.out[row] = silu_f(v0) * up;
+      break;
+    }
+    case EPI_V_CACHE: {
+      const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
+      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
+      break;
+    }
+    case EPI_MOE_SWIGLU: {
+      for (int e = 0; 2 * e + 1 < S.npass; e++) {
+        float g = rowval(2 * e, t), up = rowval(2 * e + 1, t);
+        float* o = e == 0 ? S.out : S.out2;
+        o[row] = silu_f(g) * up;
+      }
+      break;
+    }
+    case EPI_MOE_DOWN: {
+      float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
+      for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
+      S.out[row] = acc + S.resid[row];
+      break;
+    }
+    default: break;
+  }
+}
+
+// MAXT: launch bound.  Q4_K / Q8_0 / Q4_0 fit 128 VGPRs (16 waves per CU, up to 1024-thread workgroups
+// for K = 28672); the formats with more planes per unit get 512-thread bounds and more registers.
+template <uint32_t MASK, int MAXT>
+__global__ void __launch_bounds__(MAXT) mv_kernel(const MvLaunch L) {
+  __shared__ float red[kRedFloats];
+  __shared__ float wsum[16];
+  int s = 0;
+  const uint32_t bid = blockIdx.x;
+  if (L.nseg > 1 && bid >= L.seg[1].wg_begin) s = 1;
+  if (L.nseg > 2 && bid >= L.seg[2].wg_begin) s = 2;
+  const MvSeg& S = L.seg[s];
+  const uint32_t wg = bid - S.wg_begin;
+  float inv = 1.0f;
+  if (L.do_norm) inv = block_inv_rms(S.pass[0].x, L.k, L.eps, wsum);
+  switch (S.type) {
+    case LGH_TYPE_Q4_K: if constexpr (MASK & M_Q4K) mv_rows<FmtQ4K>(L, S, wg, inv, red); break;
+    case LGH_TYPE_Q5_K: if constexpr (MASK & M_Q5K) mv_rows<FmtQ5K>(L, S, wg, inv, red); break;
+    case LGH_TYPE_Q6_K: if constexpr (MASK & M_Q6K) mv_rows<FmtQ6K>(L, S, wg, inv, red); break;
+    case LGH_TYPE_Q8_0: if constexpr (MASK & M_Q80) mv_rows<FmtQ80>(L, S, wg, inv, red); break;
+    case LGH_TYPE_Q4_0: if constexpr (MASK & M_Q40) mv_rows<FmtQ40>(L, S, wg, inv, red); break;
+    default: break;
+  }
+  __syncthreads();
+  mv_epilogue(L, S, wg, red);
+}
+
+static uint32_t type_mask(int t) {
+  switch (t) {
+    case LGH_TYPE_Q4_K: return M_Q4K; case LGH_TYPE_Q5_K: return M_Q5K; case LGH_TYPE_Q6_K: return M_Q6K;
+    case LGH_TYPE_Q8_0: return M_Q80; case LGH_TYPE_Q4_0: return M_Q40; default: return 0;
+  }
+}
+
+static uint32_t unit_elems(int t) { return t == LGH_TYPE_Q6_K ? 64u : 32u; }
+static uint32_t rows_in_flight(int t) {
+  switch (t) {
+    case LGH_TYPE_Q4_K: return FmtQ4K::B; case LGH_TYPE_Q5_K: return FmtQ5K::B; case LGH_TYPE_Q6_K: return FmtQ6K::B;
+    case LGH_TYPE_Q8_0: return FmtQ80::B; case LGH_TYPE_Q4_0: return FmtQ40::B; default: return 1;
+  }
+}
+
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan) {
+  if (!type_mask(dev_type) || k == 0 || n_rows == 0 || npass < 1 || npass > 4) return hipErrorInvalidValue;
+  uint32_t ue = unit_elems(dev_type);
+  if (k % ue) return hipErrorInvalidValue;
+  uint32_t units = k / ue;
+  uint32_t T = (units + 63) / 64;
+  const uint32_t maxT = (dev_type == LGH_TYPE_Q5_K || dev_type == LGH_TYPE_Q6_K) ? 8u : 16u;
+  if (T > maxT) return hipErrorInvalidValue;  // K beyond every supported model (see launch bounds below)
+  uint32_t G = T == 1 ? 4 : (T == 2 ? 2 : 1);
+  uint32_t B = rows_in_flight(dev_type);
+  uint32_t occ = 16 / (T * G);
+  if (occ < 1) occ = 1;
+  if (occ > 4) occ = 4;
+  uint32_t rpg = B;
+  const uint32_t max_wg = kNumCU * occ * 4;
+  while ((n_rows + G * rpg - 1) / (G * rpg) > max_wg && (uint32_t)npass * T * G * (rpg + B) <= (uint32_t)kRedFloats)
+    rpg += B;
+  while ((uint32_t)npass * T * G * rpg > (uint32_t)kRedFloats && rpg > 2) rpg -= 2;
+  if (rpg & 1) rpg += 1;
+  plan->units = units;
+  plan->T = T;
+  plan->G = G;
+  plan->rows_per_wg = G * rpg;
+  plan->n_wg = (n_rows + plan->rows_per_wg - 1) / plan->rows_per_wg;
+  plan->threads = T * G * 64;
+  return hipSuccess;
+}
+
+hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+  uint32_t mask = 0;
+  for (int i = 0; i < L.nseg; i++) mask |= type_mask(L.seg[i].type);
+  if (!mask || n_wg == 0 || threads == 0) return hipErrorInvalidValue;
+  const bool wide = (mask & ~(M_Q4K | M_Q80 | M_Q40)) == 0;  // 1024-thread-capable instantiations
+  if (threads > (wide ? 1024u : 512u)) return hipErrorInvalidValue;
+  dim3 grid(n_wg), block(threads);
+  if (mask == M_Q4K) hipLaunchKernelGGL((mv_kernel<M_Q4K, 1024>), grid, block, 0, st, L);
+  else if (mask == M_Q80) hipLaunchKernelGGL((mv_kernel<M_Q80, 1024>), grid, block, 0, st, L);
+  else if (mask == M_Q40) hipLaunchKernelGGL((mv_kernel<M_Q40, 1024>), grid, block, 0, st, L);
+  else if (mask == M_Q5K) hipLaunchKernelGGL((mv_kernel<M_Q5K, 512>), grid, block, 0, st, L);
+  else if (mask == M_Q6K) hipLaunchKernelGGL((mv_kernel<M_Q6K, 512>), grid, block, 0, st, L);
+  else if (mask == (M_Q4K | M_Q6K)) hipLaunchKernelGGL((mv_kernel<M_Q4K | M_Q6K, 512>), grid, block, 0, st, L);
+  else if (mask == (M_Q5K | M_Q6K)) hipLaunchKernelGGL((mv_kernel<M_Q5K | M_Q6K, 512>), grid, block, 0, st, L);
+  else hipLaunchKernelGGL((mv_kernel<M_ALL, 512>), grid, block, 0, st, L);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------ F32
+// f32 weights (MoE router, and every GGUF type the engine dequantizes at upload): one wave per row,
+// float4 loads, x from L2.  The reference's `vec_mat` sums strictly sequentially (ops.rs:993-999);
+// here lanes stride K and meet in a wave reduction.
+__global__ void __launch_bounds__(256) f32_matvec_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                         float* out, uint32_t k, uint32_t n, const float* norm_w, float eps,
+                                                         const float* resid) {
+  __shared__ float wsum[16];
+  float inv = 1.0f;
+  if (norm_w) inv = block_inv_rms(x, k, eps, wsum);
+  const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* wr = w + (size_t)row * k;
+  float acc = 0.0f;
+  for (uint32_t i = lane * 4; i < k; i += 256) {
+    f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wr + i));
+    f32x4 xv = *reinterpret_cast<const f32x4*>(x + i);
+    if (norm_w) xv = (xv * inv) * *reinterpret_cast<const f32x4*>(norm_w + i);
+    acc = __builtin_fmaf(wv.x, xv.x, acc);
+    acc = __builtin_fmaf(wv.y, xv.y, acc);
+    acc = __builtin_fmaf(wv.z, xv.z, acc);
+    acc = __builtin_fmaf(wv.w, xv.w, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[row] = resid ? acc + resid[row] : acc;
+}
+
+hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
+                             float eps, const float* resid, hipStream_t st) {
+  if (k % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(f32_matvec_kernel, dim3((n + 3) / 4), dim3(256), 0, st, w, x, out, k, n, norm_w, eps, resid);
+  return hipGetLastError();
+}
+
+}  // namespace lgh

@@ -1,0 +1,229 @@
+// misc.hip — small decode-path kernels: standalone RMSNorm / RoPE / SiLU*mul (per-op surface and
+// fallbacks for shapes the fused epilogues do not cover), device arg-max, MoE router.
+#include "device_utils.h"
+
+namespace lgh {
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm  (simd.rs:847-878; CUDA twin rms_norm_fused, kernels.rs:131-168): one workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) rms_norm_kernel(const float* __restrict__ x, const float* __restrict__ w, float eps,
+                                                        float* __restrict__ out, uint32_t n) {
+  __shared__ float wsum[16];
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  float ss = 0.0f;
+  for (uint32_t i = tid; i < n; i += nthr) ss = __builtin_fmaf(x[i], x[i], ss);
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+  __syncthreads();
+  float tot = 0.0f;
+  for (uint32_t i = 0; i < (nthr >> 6); i++) tot += wsum[i];
+  const float inv = 1.0f / __builtin_sqrtf(tot / (float)n + eps);
+  for (uint32_t i = tid; i < n; i += nthr) out[i] = x[i] * inv * w[i];
+}
+
+hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st) {
+  uint32_t thr = n >= 4096 ? 1024 : 256;
+  hipLaunchKernelGGL(rms_norm_kernel, dim3(1), dim3(thr), 0, st, x, w, eps, out, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// RoPE at one position (ops.rs:1285-1337; CUDA twin rope_single_pos, kernels.rs:379-429).  cos/sin
+// come from the host-built table (libm powf/cosf/sinf, the reference's own arithmetic), so given the
+// same q/k the rotation is bit-exact.  One thread per pair.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rope_kernel(float* q, float* k, uint32_t n_heads, uint32_t n_kv, uint32_t d,
+                                                   const int* pos_ptr, const float* __restrict__ cs, int neox) {
+  const uint32_t half = d / 2;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t total = (n_heads + n_kv) * half;
+  if (t >= total) return;
+  const uint32_t head = t / half, i = t % half;
+  float* base = head < n_heads ? q + (size_t)head * d : k + (size_t)(head - n_heads) * d;
+  const uint32_t pos = (uint32_t)*pos_ptr;
+  const float c = cs[((size_t)pos * half + i) * 2], s = cs[((size_t)pos * half + i) * 2 + 1];
+  const uint32_t i0 = neox ? i : 2 * i, i1 = neox ? i + half : 2 * i + 1;
+  const float x0 = base[i0], x1 = base[i1];
+  base[i0] = x0 * c - x1 * s;
+  base[i1] = x0 * s + x1 * c;
+}
+
+hipError_t rope_launch(float* q, float* k, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, const int* pos,
+                       const float* rope_cs, int neox, hipStream_t st) {
+  uint32_t total = (n_heads + n_kv) * (head_dim / 2);
+  hipLaunchKernelGGL(rope_kernel, dim3((total + 255) / 256), dim3(256), 0, st, q, k, n_heads, n_kv, head_dim, pos, rope_cs,
+                     neox);
+  return hipGetLastError();
+}
+
+// simd.rs:598-649: gate[i] = gate[i] / (1 + exp(-gate[i])) * up[i]
+__global__ void __launch_bounds__(256) silu_mul_kernel(const float* __restrict__ gate, const float* __restrict__ up,
+                                                       float* __restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float g = gate[i];
+    out[i] = g / (1.0f + expf(-g)) * up[i];
+  }
+}
+
+hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL(silu_mul_kernel, dim3((n + 255) / 256), dim3(256), 0, st, gate, up, out, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Arg-max with the reference's tie rule: Iterator::max_by returns the LAST maximal element
+// (src/main.rs:1815-1821).  Stage 1: 64 workgroups -> partials; stage 2: one workgroup -> state.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void amax_merge(float& bv, int& bi, float v, int i) {
+  if (v > bv || (v == bv && i > bi)) { bv = v; bi = i; }
+}
+
+__device__ __forceinline__ void amax_block_reduce(float& bv, int& bi, float* sv, int* si) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float ov = __shfl_xor(bv, off, 64);
+    int oi = __shfl_xor(bi, off, 64);
+    amax_merge(bv, bi, ov, oi);
+  }
+  const uint32_t tid = threadIdx.x;
+  if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (uint32_t w = 1; w < (blockDim.x >> 6); w++) amax_merge(bv, bi, sv[w], si[w]);
+  }
+}
+
+constexpr int kArgmaxParts = 64;
+
+__global__ void __launch_bounds__(256) argmax_stage1(const float* __restrict__ v, uint32_t n, float* pv, int* pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  float bv = -INFINITY;
+  int bi = -1;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) amax_merge(bv, bi, v[i], (int)i);
+  amax_block_reduce(bv, bi, sv, si);
+  if (threadIdx.x == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; }
+}
+
+__global__ void __launch_bounds__(64) argmax_stage2(const float* pv, const int* pi, int nparts, int* state, int* out_token) {
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = threadIdx.x; i < nparts; i += 64) amax_merge(bv, bi, pv[i], pi[i]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float ov = __shfl_xor(bv, off, 64);
+    int oi = __shfl_xor(bi, off, 64);
+    amax_merge(bv, bi, ov, oi);
+  }
+  if (threadIdx.x == 0) {
+    if (bi < 0) bi = 0;
+    if (state) { state[ST_ARGMAX] = bi; state[ST_TOKEN] = bi; }  // feed the token back on device
+    if (out_token) out_token[state ? state[ST_POS] : 0] = bi;      // token log, indexed by position
+  }
+}
+
+hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(argmax_stage1, dim3(kArgmaxParts), dim3(256), 0, st, logits, n, part_val, part_idx);
+  hipLaunchKernelGGL(argmax_stage2, dim3(1), dim3(64), 0, st, part_val, part_idx, kArgmaxParts, state, out_token);
+  return hipGetLastError();
+}
+
+// K/V rows of the current token into the caches (layers.rs:577-600; CUDA twin update_kv_cache,
+// kernels.rs:800-817) — only used when RoPE + cache write are not fused into the QKV launch.
+__global__ void __launch_bounds__(256) kv_store_kernel(const float* __restrict__ k, const float* __restrict__ v, float* kcache,
+                                                       float* vcache, uint32_t n_kv, uint32_t d, uint32_t max_seq,
+                                                       const int* pos_ptr) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_kv * d) return;
+  const uint32_t h = i / d, j = i % d, pos = (uint32_t)*pos_ptr;
+  const size_t dst = ((size_t)h * max_seq + pos) * d + j;
+  kcache[dst] = k[i];
+  vcache[dst] = v[i];
+}
+
+hipError_t kv_store_launch(const float* k, const float* v, float* kcache, float* vcache, uint32_t n_kv, uint32_t d,
+                           uint32_t max_seq, const int* pos, hipStream_t st) {
+  hipLaunchKernelGGL(kv_store_kernel, dim3((n_kv * d + 255) / 256), dim3(256), 0, st, k, v, kcache, vcache, n_kv, d, max_seq, pos);
+  return hipGetLastError();
+}
+
+// pipeline stages without an embedding open the token here
+__global__ void advance_kernel(int* state) {
+  int p = state[ST_NEXT];
+  state[ST_POS] = p;
+  state[ST_NEXT] = p + 1;
+}
+
+hipError_t advance_launch(int* state, hipStream_t st) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, state);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// MoE router (moe.rs:128-198; CUDA path gpu_only.rs:1765-1831 does this on the HOST after a D2H):
+// logits[e] = <rms_norm(h), W_r[e]>, stable descending sort, top-k, softmax over the k logits.
+// One workgroup; wave e handles experts e, e+nwaves, ...
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxExperts = 64;
+
+__global__ void __launch_bounds__(512) moe_router_kernel(const float* __restrict__ x, const float* __restrict__ norm_w,
+                                                         float eps, const float* __restrict__ w, uint32_t hidden,
+                                                         uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w) {
+  __shared__ float wsum[16];
+  __shared__ float logits[kMaxExperts];
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  float inv = 1.0f;
+  if (norm_w) {
+    float ss = 0.0f;
+    for (uint32_t i = tid; i < hidden; i += blockDim.x) ss = __builtin_fmaf(x[i], x[i], ss);
+    ss = wave_sum(ss);
+    if (lane == 0) wsum[wave] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    for (uint32_t i = 0; i < nw; i++) tot += wsum[i];
+    inv = 1.0f / __builtin_sqrtf(tot / (float)hidden + eps);
+  }
+  for (uint32_t e = wave; e < n_experts; e += nw) {
+    const float* we = w + (size_t)e * hidden;
+    float acc = 0.0f;
+    for (uint32_t i = lane; i < hidden; i += 64) {
+      float xv = norm_w ? x[i] * inv * norm_w[i] : x[i];
+      acc = __builtin_fmaf(xv, we[i], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) logits[e] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // stable descending selection: ties keep the lower expert index first (slice::sort_by is stable)
+    uint64_t taken = 0;
+    float top[8];
+    float mx = -INFINITY;
+    for (uint32_t s = 0; s < top_k; s++) {
+      int best = -1;
+      for (uint32_t e = 0; e < n_experts; e++) {
+        if ((taken >> e) & 1) continue;
+        if (best < 0 || logits[e] > logits[best]) best = (int)e;
+      }
+      taken |= 1ull << best;
+      sel[s] = best;
+      top[s] = logits[best];
+      mx = fmaxf(mx, top[s]);
+    }
+    float exp_sum = 0.0f;
+    for (uint32_t s = 0; s < top_k; s++) exp_sum += expf(top[s] - mx);
+    for (uint32_t s = 0; s < top_k; s++) sel_w[s] = expf(top[s] - mx) / exp_sum;
+  }
+}
+
+hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
+                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st) {
+  if (n_experts > (uint32_t)kMaxExperts || top_k > 8 || top_k > n_experts) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moe_router_kernel, dim3(1), dim3(512), 0, st, x, norm_w, eps, w, hidden, n_experts, top_k, sel, sel_w);
+  return hipGetLastError();
+}
+
+}  // namespace lgh

@@ -1,0 +1,222 @@
+// ops_api.hip — the per-op C entry points (host tensors in / host tensors out) that mirror the
+// reference's `Backend` trait ops on the decode path (src/backend/mod.rs:29-265), plus the kernel
+// micro-benchmark.  They run the SAME kernels the engine runs, on a throw-away context, so that each
+// kernel can be checked against the CPU backend in isolation.
+#include "engine.h"
+
+#include <cmath>
+#include <vector>
+
+using namespace lgh;
+
+namespace {
+
+struct Tmp {  // bare context: stream, device state words, tracked allocations
+  lgh_ctx* c = nullptr;
+  int rc = LGH_OK;
+  explicit Tmp(int device) {
+    int n = lgh_device_count();
+    if (n <= 0 || device < 0 || device >= n) { rc = LGH_NOT_AVAILABLE; return; }
+    c = new lgh_ctx();
+    c->device = device;
+    c->d.norm_eps = 1e-5f;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      rc = LGH_INITIALIZATION_FAILED;
+      delete c;
+      c = nullptr;
+      return;
+    }
+    c->stream = c->own_stream;
+    if ((rc = dev_alloc(c, (void**)&c->state, ST_WORDS * 4))) return;
+    (void)hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream);
+  }
+  ~Tmp() {
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+  }
+  float* up(const float* host, size_t n) {  // device copy of a host f32 vector (nullptr on failure)
+    float* d = nullptr;
+    if (dev_alloc(c, (void**)&d, n * 4)) return nullptr;
+    if (host && hipMemcpyAsync(d, host, n * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return nullptr;
+    return d;
+  }
+  int down(float* host, const float* dev, size_t n) {
+    if (hipMemcpyAsync(host, dev, n * 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+    return hipStreamSynchronize(c->stream) == hipSuccess ? LGH_OK : LGH_OPERATION_FAILED;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int lgh_op_dequantize(int device, uint32_t type, const void* src, size_t n, float* dst) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  const uint32_t be = blk_elems((int)type);
+  if (!be || n % be) return LGH_UNSUPPORTED_DTYPE;
+  const size_t nbytes = n / be * blk_bytes((int)type);
+  uint8_t* raw = nullptr;
+  float* out = nullptr;
+  if (dev_alloc(t.c, (void**)&raw, nbytes) || dev_alloc(t.c, (void**)&out, n * 4)) return LGH_ALLOCATION_FAILED;
+  if (hipMemcpyAsync(raw, src, nbytes, hipMemcpyHostToDevice, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  if (dequant_launch((int)type, raw, out, n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(dst, out, n);
+}
+
+static int vec_mat_impl(int device, uint32_t type, const void* w, const void* w2, const float* x, const float* norm_w,
+                        float eps, const float* resid, float* out, size_t k, size_t n) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  t.c->d.norm_eps = eps;
+  const uint32_t be = blk_elems((int)type);
+  if (!be || k % be) return LGH_SHAPE_MISMATCH;
+  const size_t nbytes = n * (k / be) * blk_bytes((int)type);
+  DevWeight W, W2;
+  int rc;
+  if ((rc = upload_matrix(t.c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
+  if (w2 && (rc = upload_matrix(t.c, W2, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w2, nbytes))) return rc;
+  float* dx = t.up(x, k);
+  float* dnw = norm_w ? t.up(norm_w, k) : nullptr;
+  float* dres = resid ? t.up(resid, n) : nullptr;
+  float* dout = t.up(nullptr, n);
+  if (!dx || !dout || (norm_w && !dnw) || (resid && !dres)) return LGH_ALLOCATION_FAILED;
+  if (w2) {
+    if (!fused_type(W.type)) return LGH_UNSUPPORTED;
+    SegSpec sp;
+    sp.npass = 2;
+    sp.W[0] = &W; sp.W[1] = &W2;
+    sp.x[0] = sp.x[1] = dx;
+    sp.epi = EPI_SWIGLU;
+    sp.out = dout;
+    if ((rc = launch_mv(t.c, LGH_K_GATEUP, &sp, 1, dnw, (uint32_t)k))) return rc;
+  } else if ((rc = linear_any(t.c, LGH_K_MISC, W, dx, dout, dnw, dres, nullptr))) {
+    return rc;
+  }
+  return t.down(out, dout, n);
+}
+
+int lgh_op_vec_mat(int device, uint32_t type, const void* w, const float* x, float* out, size_t k, size_t n) {
+  return vec_mat_impl(device, type, w, nullptr, x, nullptr, 1e-5f, nullptr, out, k, n);
+}
+
+int lgh_op_norm_vec_mat(int device, uint32_t type, const void* w, const float* x, const float* norm_w, float eps, float* out,
+                        size_t k, size_t n) {
+  return vec_mat_impl(device, type, w, nullptr, x, norm_w, eps, nullptr, out, k, n);
+}
+
+int lgh_op_swiglu_vec_mat(int device, uint32_t type, const void* w_gate, const void* w_up, const float* x,
+                          const float* norm_w, float eps, float* out, size_t k, size_t n) {
+  return vec_mat_impl(device, type, w_gate, w_up, x, norm_w, eps, nullptr, out, k, n);
+}
+
+int lgh_op_rms_norm(int device, const float* x, const float* w, float eps, float* out, size_t n) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  float *dx = t.up(x, n), *dw = t.up(w, n), *dout = t.up(nullptr, n);
+  if (!dx || !dw || !dout) return LGH_ALLOCATION_FAILED;
+  if (rms_norm_launch(dx, dw, eps, dout, (uint32_t)n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, n);
+}
+
+int lgh_op_rope(int device, float* q, float* k, size_t n_heads, size_t n_kv, size_t d, size_t pos, float freq_base,
+                float freq_scale, int neox) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  const size_t half = d / 2;
+  std::vector<float> cs(half * 2);  // table row for `pos`, reference arithmetic (ops.rs:1300-1313)
+  const float position = (float)pos / freq_scale;
+  for (size_t i = 0; i < half; i++) {
+    const float freq = 1.0f / std::pow(freq_base, (float)(2 * i) / (float)d);
+    const float theta = position * freq;
+    cs[2 * i] = std::cos(theta);
+    cs[2 * i + 1] = std::sin(theta);
+  }
+  float *dq = t.up(q, n_heads * d), *dk = t.up(k, n_kv * d), *dcs = t.up(cs.data(), cs.size());
+  if (!dq || !dk || !dcs) return LGH_ALLOCATION_FAILED;
+  // state[ST_POS] stays 0: the one-row table is indexed at position 0
+  if (rope_launch(dq, dk, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, t.c->state + ST_POS, dcs, neox, t.c->stream) != hipSuccess)
+    return LGH_OPERATION_FAILED;
+  int rc = t.down(q, dq, n_heads * d);
+  if (rc) return rc;
+  return t.down(k, dk, n_kv * d);
+}
+
+int lgh_op_attention_cached(int device, const float* q, const float* kc, const float* vc, float* out, size_t n_heads,
+                            size_t n_kv, size_t d, size_t max_seq, float scale, size_t kv_len, int n_splits) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (kv_len == 0 || kv_len > max_seq || n_kv == 0 || n_heads % n_kv) return LGH_INVALID_ARGUMENT;
+  if (n_splits <= 0) n_splits = 8;
+  const size_t g = n_heads / n_kv, cache = n_kv * max_seq * d;
+  float *dq = t.up(q, n_heads * d), *dk = t.up(kc, cache), *dv = t.up(vc, cache), *dout = t.up(nullptr, n_heads * d);
+  float *pml = t.up(nullptr, n_kv * n_splits * g * 2), *pacc = t.up(nullptr, n_kv * n_splits * g * d);
+  if (!dq || !dk || !dv || !dout || !pml || !pacc) return LGH_ALLOCATION_FAILED;
+  if (attn_launch(dq, dk, dv, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)max_seq, scale, nullptr, (int)kv_len,
+                  (uint32_t)n_splits, pml, pacc, t.c->stream) != hipSuccess)
+    return LGH_UNSUPPORTED;
+  if (attn_combine_launch(pml, pacc, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)n_splits, dout, t.c->stream) != hipSuccess)
+    return LGH_OPERATION_FAILED;
+  return t.down(out, dout, n_heads * d);
+}
+
+int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, size_t n) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  float *dg = t.up(gate, n), *du = t.up(up, n), *dout = t.up(nullptr, n);
+  if (!dg || !du || !dout) return LGH_ALLOCATION_FAILED;
+  if (silu_mul_launch(dg, du, dout, (uint32_t)n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, n);
+}
+
+int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, size_t k, size_t n, int mode, int iters,
+                      double* avg_us) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!avg_us || iters <= 0) return LGH_INVALID_ARGUMENT;
+  const uint32_t be = blk_elems((int)type);
+  if (!be || k % be) return LGH_SHAPE_MISMATCH;
+  const size_t nbytes = n * (k / be) * blk_bytes((int)type);
+  DevWeight W, W2;
+  int rc;
+  if ((rc = upload_matrix(t.c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
+  if (mode == 2 && (rc = upload_matrix(t.c, W2, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w2 ? w2 : w, nbytes))) return rc;
+  std::vector<float> hx(k), hw(k, 1.0f);
+  for (size_t i = 0; i < k; i++) hx[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
+  float *dx = t.up(hx.data(), k), *dnw = t.up(hw.data(), k), *dout = t.up(nullptr, n);
+  if (!dx || !dnw || !dout) return LGH_ALLOCATION_FAILED;
+  auto once = [&]() -> int {
+    if (mode == 2) {
+      SegSpec sp;
+      sp.npass = 2;
+      sp.W[0] = &W; sp.W[1] = &W2;
+      sp.x[0] = sp.x[1] = dx;
+      sp.epi = EPI_SWIGLU;
+      sp.out = dout;
+      return launch_mv(t.c, LGH_K_GATEUP, &sp, 1, dnw, (uint32_t)k);
+    }
+    return linear_any(t.c, LGH_K_MISC, W, dx, dout, mode == 1 ? dnw : nullptr, nullptr, nullptr);
+  };
+  for (int i = 0; i < 3; i++)
+    if ((rc = once())) return rc;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return LGH_OPERATION_FAILED;
+  (void)hipEventRecord(a, t.c->stream);
+  for (int i = 0; i < iters; i++)
+    if ((rc = once())) break;
+  (void)hipEventRecord(b, t.c->stream);
+  hipError_t e = hipEventSynchronize(b);
+  float ms = 0.0f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (rc) return rc;
+  if (e != hipSuccess) return LGH_OPERATION_FAILED;
+  *avg_us = (double)ms * 1000.0 / iters;
+  return LGH_OK;
+}
+
+}  // extern "C"

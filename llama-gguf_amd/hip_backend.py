@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's GPU-engine interface over the C ABI (include/llama_gguf_hip.h).
+
+The reference drives every GPU engine through ``trait GpuInference`` (src/backend/mod.rs:283-296:
+``forward / prefill_token / reset / position``), builds it with ``from_model(model, max_seq_len)``
+(src/backend/cuda/gpu_only.rs:426) and adapts it to ``trait Model`` with ``GpuModelWrapper``
+(src/backend/mod.rs:302-364).  The reference is Rust and this image has no Rust toolchain, so the
+Rust shim is shipped as source in INTEGRATION.md; this module is the same surface — same names,
+argument meaning and error behaviour — for the tests and the benchmark.  Nothing here computes: every
+call goes through ``lib/libllama_gguf_hip.so`` and FAILS LOUDLY if that library or a GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip.so")
+
+# every symbol include/llama_gguf_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "lgh_device_count", "lgh_create", "lgh_upload_tensor", "lgh_finalize", "lgh_destroy", "lgh_forward",
+    "lgh_prefill_token", "lgh_prefill_batch", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
+    "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
+    "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
+    "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
+    "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat",
+)
+
+K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
+K_COUNT = 16
+FLAG_NO_GRAPH = 1
+
+
+class BackendError(RuntimeError):
+    """The reference's BackendError (src/backend/error.rs:3-37); `.variant` names the Rust variant."""
+    VARIANTS = {1: "NotAvailable", 2: "ShapeMismatch", 3: "DTypeMismatch", 4: "UnsupportedDType", 5: "Unsupported",
+                6: "InvalidArgument", 7: "Tensor", 8: "InitializationFailed", 9: "AllocationFailed",
+                10: "OperationFailed"}
+
+    def __init__(self, status: int, message: str = ""):
+        self.status = status
+        self.variant = self.VARIANTS.get(status, f"Status{status}")
+        super().__init__(f"{self.variant}: {message}" if message else self.variant)
+
+
+class ModelDesc(C.Structure):
+    _fields_ = ([(n, C.c_uint32) for n in (
+        "struct_size", "hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+        "vocab_size", "max_seq_len", "num_experts", "num_experts_per_token", "expert_intermediate_size",
+        "use_neox_rope")]
+                + [(n, C.c_float) for n in ("norm_eps", "rope_freq_base", "rope_freq_scale")]
+                + [("device_id", C.c_int32), ("layer_begin", C.c_uint32), ("layer_end", C.c_uint32),
+                   ("flags", C.c_uint32)])
+
+
+class Stats(C.Structure):
+    _fields_ = [("weight_bytes", C.c_uint64), ("kv_bytes", C.c_uint64), ("scratch_bytes", C.c_uint64),
+                ("tokens_processed", C.c_uint64), ("graph_nodes", C.c_uint64),
+                ("k_launches", C.c_uint64 * K_COUNT), ("k_time_us", C.c_double * K_COUNT),
+                ("k_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the engine.  Raises (never falls back) when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(8, f"{LIB_PATH} is missing: build it with `make -C {_HERE}` or __graft_entry__.build()")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_float
+    sig = {
+        "lgh_device_count": (C.c_int, []),
+        "lgh_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(vp)]),
+        "lgh_upload_tensor": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(C.c_uint64), vp, sz]),
+        "lgh_finalize": (C.c_int, [vp]), "lgh_destroy": (None, [vp]),
+        "lgh_forward": (C.c_int, [vp, u32, vp]), "lgh_prefill_token": (C.c_int, [vp, u32]),
+        "lgh_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_reset": (None, [vp]), "lgh_position": (sz, [vp]),
+        "lgh_forward_argmax": (C.c_int, [vp, u32, C.POINTER(u32)]),
+        "lgh_decode_greedy": (C.c_int, [vp, u32, sz, vp]),
+        "lgh_last_error": (C.c_char_p, [vp]), "lgh_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "lgh_set_profiling": (C.c_int, [vp, C.c_int]), "lgh_set_stream": (C.c_int, [vp, vp]),
+        "lgh_get_stream": (vp, [vp]), "lgh_synchronize": (C.c_int, [vp]), "lgh_read_hidden": (C.c_int, [vp, vp]),
+        "lgh_stage_hidden_buffer": (C.c_int, [vp, C.POINTER(vp)]),
+        "lgh_stage_forward": (C.c_int, [vp, u32, C.c_int, vp, C.POINTER(u32)]),
+        "lgh_op_dequantize": (C.c_int, [C.c_int, u32, vp, sz, vp]),
+        "lgh_op_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, sz, sz]),
+        "lgh_op_rms_norm": (C.c_int, [C.c_int, vp, vp, f32, vp, sz]),
+        "lgh_op_rope": (C.c_int, [C.c_int, vp, vp, sz, sz, sz, sz, f32, f32, C.c_int]),
+        "lgh_op_attention_cached": (C.c_int, [C.c_int, vp, vp, vp, vp, sz, sz, sz, sz, f32, sz, C.c_int]),
+        "lgh_op_silu_mul": (C.c_int, [C.c_int, vp, vp, vp, sz]),
+        "lgh_op_norm_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, f32, vp, sz, sz]),
+        "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
+        "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return load_library().lgh_device_count()
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _chk(status: int, what: str = "") -> None:
+    if status != 0:
+        raise BackendError(status, what)
+
+
+class HipGpuInference:
+    """`impl GpuInference for HipGpuInference` (src/backend/mod.rs:283-296), one context per GPU."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self.config = None
+        self.vocab_size = 0
+
+    # -- pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>  (gpu_only.rs:426)
+    @classmethod
+    def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
+                   flags: int = 0, attn_splits: int = 0) -> "HipGpuInference":
+        """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
+        `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
+        L = load_library()
+        self = cls()
+        cfg = model.config
+        d = ModelDesc()
+        d.struct_size = C.sizeof(ModelDesc)
+        for k in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+                  "vocab_size", "num_experts", "num_experts_per_token", "expert_intermediate_size"):
+            setattr(d, k, int(getattr(cfg, k)))
+        d.max_seq_len = int(max_seq_len)
+        d.use_neox_rope = int(cfg.use_neox_rope)
+        d.norm_eps, d.rope_freq_base, d.rope_freq_scale = cfg.norm_eps, cfg.rope_freq_base, cfg.rope_freq_scale
+        d.device_id = device
+        lb, le = (0, cfg.num_layers) if layer_range is None else (layer_range[0], layer_range[1])
+        d.layer_begin, d.layer_end = lb, le
+        d.flags = flags | ((attn_splits & 0xFF) << 8)
+        _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
+        self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
+        try:
+            for name, t, ne, data in model.tensors(range(lb, le)):
+                self.upload_tensor(name, t, ne, data)
+            self._call(L.lgh_finalize(self._h))
+        except Exception:
+            self.close()
+            raise
+        return self
+
+    def upload_tensor(self, name: str, ggml_type: int, ne: Iterable[int], data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data)
+        ne = list(ne)
+        ne4 = (C.c_uint64 * 4)(*(ne + [0] * (4 - len(ne))))
+        self._call(load_library().lgh_upload_tensor(self._h, name.encode(), ggml_type, ne4, data.ctypes.data, data.nbytes))
+
+    def _call(self, status: int) -> None:
+        if status != 0:
+            raise BackendError(status, load_library().lgh_last_error(self._h).decode())
+
+    # -- GpuInference
+    def forward(self, token_id: int) -> np.ndarray:
+        logits = np.empty(self.vocab_size, dtype=np.float32)
+        self._call(load_library().lgh_forward(self._h, token_id, logits.ctypes.data))
+        return logits
+
+    def prefill_token(self, token_id: int) -> None:
+        self._call(load_library().lgh_prefill_token(self._h, token_id))
+
+    def forward_batch(self, tokens: Sequence[int]) -> None:  # gpu_only.rs:776-790 minus the final forward
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+        self._call(load_library().lgh_prefill_batch(self._h, toks.ctypes.data, toks.size))
+
+    def reset(self) -> None:
+        load_library().lgh_reset(self._h)
+
+    def position(self) -> int:
+        return load_library().lgh_position(self._h)
+
+    # -- bench fast paths
+    def forward_argmax(self, token_id: int) -> int:
+        nxt = C.c_uint32()
+        self._call(load_library().lgh_forward_argmax(self._h, token_id, C.byref(nxt)))
+        return nxt.value
+
+    def decode_greedy(self, first_token: int, n_steps: int) -> np.ndarray:
+        out = np.zeros(n_steps, dtype=np.uint32)
+        self._call(load_library().lgh_decode_greedy(self._h, first_token, n_steps, out.ctypes.data))
+        return out
+
+    # -- pipeline stage
+    def stage_hidden_ptr(self) -> int:
+        p = C.c_void_p()
+        self._call(load_library().lgh_stage_hidden_buffer(self._h, C.byref(p)))
+        return p.value
+
+    def stage_forward(self, token_id: int = 0, want_logits: bool = False, argmax: bool = False):
+        logits = np.empty(self.vocab_size, dtype=np.float32) if (want_logits and not argmax) else None
+        nxt = C.c_uint32()
+        self._call(load_library().lgh_stage_forward(
+            self._h, token_id, int(want_logits), logits.ctypes.data if logits is not None else None,
+            C.byref(nxt) if (want_logits and argmax) else None))
+        return nxt.value if (want_logits and argmax) else logits
+
+    def set_stream(self, stream_handle: int) -> None:
+        self._call(load_library().lgh_set_stream(self._h, stream_handle))
+
+    def synchronize(self) -> None:
+        self._call(load_library().lgh_synchronize(self._h))
+
+    def read_hidden(self) -> np.ndarray:
+        out = np.empty(self.hidden_size, dtype=np.float32)
+        self._call(load_library().lgh_read_hidden(self._h, out.ctypes.data))
+        return out
+
+    def set_profiling(self, on: bool) -> None:
+        self._call(load_library().lgh_set_profiling(self._h, int(on)))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._call(load_library().lgh_get_stats(self._h, C.byref(s)))
+        out = {k: getattr(s, k) for k in ("weight_bytes", "kv_bytes", "scratch_bytes", "tokens_processed",
+                                          "graph_nodes", "step_alg_bytes")}
+        out["kernels"] = {K_NAMES[i]: {"launches": s.k_launches[i], "time_us": s.k_time_us[i],
+                                       "alg_bytes": s.k_alg_bytes[i]}
+                          for i in range(len(K_NAMES)) if s.k_launches[i]}
+        return out
+
+    def close(self) -> None:
+        if self._h:
+            load_library().lgh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class InferenceContext:
+    """The fields of the reference's InferenceContext that GpuModelWrapper touches (model/mod.rs:222-326)."""
+
+    def __init__(self):
+        self.position = 0
+        self.kv_seq_len = 0
+
+    def reset(self) -> None:
+        self.position = 0
+        self.kv_seq_len = 0
+
+
+class GpuModelWrapper:
+    """GpuModelWrapper<T: GpuInference> (src/backend/mod.rs:302-364): adapts the engine to `Model::forward`."""
+
+    def __init__(self, gpu: HipGpuInference, config=None):
+        self.gpu = gpu
+        self.config = config if config is not None else gpu.config
+
+    def forward(self, tokens: Sequence[int], ctx: InferenceContext) -> np.ndarray:
+        if ctx.position == 0 and self.gpu.position() > 0:  # mod.rs:334-336
+            self.gpu.reset()
+        if len(tokens) == 0:
+            raise ValueError("No tokens to process")           # mod.rs:338-342
+        for t in tokens[:-1]:                                   # mod.rs:344-347
+            self.gpu.prefill_token(int(t))
+        logits = self.gpu.forward(int(tokens[-1]))              # mod.rs:349
+        ctx.position += len(tokens)
+        ctx.kv_seq_len = ctx.position
+        return logits
+
+
+# ---- per-op surface (the `Backend` trait ops on the path, src/backend/mod.rs:29-265) ----
+def op_dequantize(ggml_type: int, raw: np.ndarray, n_elems: int, device: int = 0) -> np.ndarray:
+    raw = np.ascontiguousarray(raw)
+    out = np.empty(n_elems, dtype=np.float32)
+    _chk(load_library().lgh_op_dequantize(device, ggml_type, raw.ctypes.data, n_elems, out.ctypes.data), "dequantize")
+    return out
+
+
+def op_vec_mat(ggml_type: int, w: np.ndarray, x, n: int, device: int = 0) -> np.ndarray:
+    w, x = np.ascontiguousarray(w), _f32(x)
+    out = np.empty(n, dtype=np.float32)
+    _chk(load_library().lgh_op_vec_mat(device, ggml_type, w.ctypes.data, x.ctypes.data, out.ctypes.data, x.size, n), "vec_mat")
+    return out
+
+
+def op_norm_vec_mat(ggml_type: int, w: np.ndarray, x, norm_w, eps: float, n: int, device: int = 0) -> np.ndarray:
+    w, x, nw = np.ascontiguousarray(w), _f32(x), _f32(norm_w)
+    out = np.empty(n, dtype=np.float32)
+    _chk(load_library().lgh_op_norm_vec_mat(device, ggml_type, w.ctypes.data, x.ctypes.data, nw.ctypes.data, eps,
+                                            out.ctypes.data, x.size, n), "norm_vec_mat")
+    return out
+
+
+def op_swiglu_vec_mat(ggml_type: int, w_gate: np.ndarray, w_up: np.ndarray, x, norm_w, eps: float, n: int,
+                      device: int = 0) -> np.ndarray:
+    wg, wu, x = np.ascontiguousarray(w_gate), np.ascontiguousarray(w_up), _f32(x)
+    nw = _f32(norm_w) if norm_w is not None else None
+    out = np.empty(n, dtype=np.float32)
+    _chk(load_library().lgh_op_swiglu_vec_mat(device, ggml_type, wg.ctypes.data, wu.ctypes.data, x.ctypes.data,
+                                              nw.ctypes.data if nw is not None else None, eps, out.ctypes.data,
+                                              x.size, n), "swiglu_vec_mat")
+    return out
+
+
+def op_rms_norm(x, w, eps: float, device: int = 0) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    out = np.empty_like(x)
+    _chk(load_library().lgh_op_rms_norm(device, x.ctypes.data, w.ctypes.data, eps, out.ctypes.data, x.size), "rms_norm")
+    return out
+
+
+def op_rope(q, k, pos: int, freq_base: float, freq_scale: float, neox: bool, device: int = 0):
+    q, k = _f32(q).copy(), _f32(k).copy()  # [n_heads, d], [n_kv, d]
+    _chk(load_library().lgh_op_rope(device, q.ctypes.data, k.ctypes.data, q.shape[0], k.shape[0], q.shape[1], pos,
+                                    freq_base, freq_scale, int(neox)), "rope")
+    return q, k
+
+
+def op_attention_cached(q, k_cache, v_cache, scale: float, kv_len: int, n_splits: int = 8, device: int = 0) -> np.ndarray:
+    q, kc, vc = _f32(q), _f32(k_cache), _f32(v_cache)  # [nh, d], [nkv, max_seq, d]
+    out = np.empty_like(q)
+    _chk(load_library().lgh_op_attention_cached(device, q.ctypes.data, kc.ctypes.data, vc.ctypes.data, out.ctypes.data,
+                                                q.shape[0], kc.shape[0], q.shape[1], kc.shape[1], scale, kv_len,
+                                                n_splits), "attention_cached")
+    return out
+
+
+def op_silu_mul(gate, up, device: int = 0) -> np.ndarray:
+    g, u = _f32(gate), _f32(up)
+    out = np.empty_like(g)
+    _chk(load_library().lgh_op_silu_mul(device, g.ctypes.data, u.ctypes.data, out.ctypes.data, g.size), "silu_mul")
+    return out
+
+
+def bench_vec_mat(ggml_type: int, w: np.ndarray, k: int, n: int, mode: int = 0, iters: int = 50,
+                  w2: Optional[np.ndarray] = None, device: int = 0) -> float:
+    """Mean device time (µs) of one fused mat-vec launch (hipEvents on the launch stream)."""
+    w = np.ascontiguousarray(w)
+    us = C.c_double()
+    _chk(load_library().lgh_bench_vec_mat(device, ggml_type, w.ctypes.data, w2.ctypes.data if w2 is not None else None,
+                                          k, n, mode, iters, C.byref(us)), "bench_vec_mat")
+    return us.value

@@ -1,0 +1,195 @@
+"""Pins the CPU oracle against every known-answer test the reference's own test-suite holds for the
+decode path.  Paths are relative to /root/reference; nothing is read from it at run time."""
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_block_sizes(orc):
+    # src/tensor/dtype.rs:217-229, src/tensor/quant/blocks.rs:293-305
+    want = {orc.Q4_0: (32, 18), orc.Q4_1: (32, 20), orc.Q5_0: (32, 22), orc.Q5_1: (32, 24), orc.Q8_0: (32, 34),
+            orc.Q8_1: (32, 36), orc.Q2_K: (256, 84), orc.Q3_K: (256, 110), orc.Q4_K: (256, 144),
+            orc.Q5_K: (256, 176), orc.Q6_K: (256, 210), orc.Q8_K: (256, 292), orc.F32: (1, 4), orc.F16: (1, 2)}
+    for t, (bs, bb) in want.items():
+        assert (orc.block_size(t), orc.block_bytes(t)) == (bs, bb)
+
+
+def test_f16_conversion_exhaustive(orc):
+    # half 2.7.1 (Cargo.lock:907) is IEEE binary16 round-to-nearest-even == numpy float16
+    h = np.arange(65536, dtype=np.uint16)
+    f = h.view(np.float16).astype(np.float32)
+    mine = np.array([orc.lib().orc_f16_to_f32(int(v)) for v in h], dtype=np.float32)
+    ok = ~np.isnan(f)
+    assert np.array_equal(mine.view(np.uint32)[ok], f.view(np.uint32)[ok])
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.standard_normal(4000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1, 100, 60000)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).view(np.uint16)
+    mine = np.array([orc.lib().orc_f32_to_f16(float(v)) for v in xs], dtype=np.uint16)
+    assert np.array_equal(mine, want)
+
+
+def test_vec_mat_gguf_layout(orc):
+    # src/backend/cpu/ops.rs:1813-1847 and 1850-1867
+    assert orc.vec_mat_f32([1, 2, 3, 4, 5, 6], [1, 1, 1], 2).tolist() == [6.0, 15.0]
+    assert orc.vec_mat_f32([1, 0, 0, 0, 1, 0], [7, 8, 9], 2).tolist() == [7.0, 8.0]
+
+
+def test_rms_norm_kats(orc):
+    # ops.rs:1636-1648; simd.rs:1200-1220; tests/integration_test.rs:175-214
+    out = orc.rms_norm([1, 2, 3, 4], [1, 1, 1, 1], 1e-5)
+    assert abs(out[0] - 0.365) < 0.01 and abs(out[3] - 1.46) < 0.01
+    out = orc.rms_norm([1, 2, 3, 4], [1, 1, 1, 1], 1e-6)
+    rms = np.sqrt(np.float32(30.0) / 4)
+    assert np.allclose(out, np.array([1, 2, 3, 4], np.float32) / rms, atol=1e-5)
+
+
+def test_rope_kats(orc):
+    # ops.rs:1689-1705: position 0 is the identity (NeoX style)
+    qd = np.array([1, 0, 1, 0, 0, 1, 0, 1], np.float32).reshape(2, 1, 4)
+    q, k = orc.rope(qd, qd, 0, 10000.0, 1.0, True)
+    assert np.allclose(q, qd, atol=1e-5) and np.allclose(k, qd, atol=1e-5)
+    # ops.rs:1708-1726: interleaved pairing, pos 1 -> q[0] = cos(1)
+    q, _ = orc.rope(np.array([1, 0, 0, 0], np.float32).reshape(1, 1, 4), np.array([1, 0, 0, 0], np.float32).reshape(1, 1, 4),
+                    1, 10000.0, 1.0, False)
+    assert abs(q.ravel()[0] - 0.54) < 0.02
+    # ops.rs:1729-1777: NeoX pairing of [1,2,3,4] at pos 1
+    x = np.array([1, 2, 3, 4], np.float32).reshape(1, 1, 4)
+    q, _ = orc.rope(x, x, 1, 10000.0, 1.0, True)
+    assert np.allclose(q.ravel(), [-1.98, 1.96, 2.46, 4.02], atol=0.05)
+
+
+def test_rope_freq_scale_divides_position(orc):
+    # ops.rs:1300: position = (pos + s) / freq_scale   (scripts/test_rope.py multiplies: not authoritative)
+    x = np.array([1, 0, 0, 0], np.float32).reshape(1, 1, 4)
+    a, _ = orc.rope(x, x, 4, 10000.0, 4.0, False)
+    b, _ = orc.rope(x, x, 1, 10000.0, 1.0, False)
+    assert np.array_equal(a, b)
+
+
+def test_dequantize_q5_kats(orc):
+    # tests/dequant_test.rs:158-212
+    d = orc.lib().orc_f32_to_f16(0.1)
+    blk = struct.pack("<H", d) + bytes(4) + bytes([0x88] * 16)
+    out = orc.dequantize(orc.Q5_0, np.frombuffer(blk, np.uint8), 32)
+    assert np.all(np.abs(out + 0.8) < 0.01)
+    blk = struct.pack("<HH", d, orc.lib().orc_f32_to_f16(1.0)) + bytes(4) + bytes([0x88] * 16)
+    out = orc.dequantize(orc.Q5_1, np.frombuffer(blk, np.uint8), 32)
+    assert np.all(np.abs(out - 1.8) < 0.01)
+
+
+ROUNDTRIP = [
+    # (type, input, bound kind, bound)  — src/tensor/quant/dequant.rs:1070-1303, tests/dequant_test.rs:8-137
+    ("Q4_0", lambda i: (i - 16.0) * 0.1, "abs", 0.15), ("Q4_1", lambda i: (i - 16.0) * 0.1 + 1.0, "abs", 0.15),
+    ("Q4_1", lambda i: i * 0.1 + 1.0, "abs", 0.15), ("Q4_1", lambda i: i * 0.1 + 5.0, "abs", 0.15),
+    ("Q5_0", lambda i: (i - 16.0) * 0.1, "abs", 0.15), ("Q5_1", lambda i: (i - 16.0) * 0.1 + 1.0, "abs", 0.15),
+    ("Q8_0", lambda i: (i - 16.0) * 0.1, "abs", 0.02), ("Q8_1", lambda i: (i - 16.0) * 0.1, "abs", 0.02),
+    ("Q2_K", lambda i: (i - 128.0) * 0.1, "rmse", 6.0), ("Q3_K", lambda i: (i - 128.0) * 0.1, "rmse", 2.5),
+    ("Q4_K", lambda i: (i - 128.0) * 0.1, "rmse", 4.5), ("Q5_K", lambda i: (i - 128.0) * 0.1, "rmse", 4.5),
+    ("Q6_K", lambda i: (i - 128.0) * 0.1, "abs", 1.0), ("Q8_K", lambda i: (i - 128.0) * 0.1, "abs", 0.1),
+]
+
+
+@pytest.mark.parametrize("tname,fn,kind,bound", ROUNDTRIP)
+def test_quantize_roundtrip_bounds(orc, tname, fn, kind, bound):
+    t = getattr(orc, tname)
+    bs = orc.block_size(t)
+    x = np.array([fn(np.float32(i)) for i in range(bs)], dtype=np.float32)
+    y = orc.dequantize(t, orc.quantize(t, x), bs)
+    if kind == "abs":
+        assert np.abs(x - y).max() < bound
+    else:
+        assert np.sqrt(np.mean((x - y) ** 2, dtype=np.float32)) < bound
+
+
+def test_quantize_zeros_and_scaling(orc):
+    # tests/dequant_test.rs:66-89 (zeros), 92-121 (large values), 124-143 (precision), 216-239 (symmetry)
+    for t in (orc.Q4_0, orc.Q8_0):
+        assert np.all(orc.dequantize(t, orc.quantize(t, np.zeros(32, np.float32)), 32) == 0.0)
+    x = (np.arange(32, dtype=np.float32) - 16.0) * 10.0
+    y = orc.dequantize(orc.Q4_0, orc.quantize(orc.Q4_0, x), 32)
+    assert np.abs(x - y).max() <= np.abs(x).max() / 7.0 * 1.1
+    x = (np.arange(32, dtype=np.float32) - 16.0) * 0.01
+    y = orc.dequantize(orc.Q8_0, orc.quantize(orc.Q8_0, x), 32)
+    assert np.sqrt(np.mean((x - y) ** 2)) < 0.005
+    p = np.arange(32, dtype=np.float32) * 0.1
+    a = orc.dequantize(orc.Q8_0, orc.quantize(orc.Q8_0, p), 32)
+    b = orc.dequantize(orc.Q8_0, orc.quantize(orc.Q8_0, -p), 32)
+    assert np.abs(a + b).max() < 0.02
+    # dequant.rs:1325-1345 batch dequantize
+    two = np.concatenate([np.arange(32, dtype=np.float32), np.arange(32, 64, dtype=np.float32)])
+    out = orc.dequantize(orc.Q4_0, orc.quantize(orc.Q4_0, two), 64)
+    assert -1 <= out[0] <= 1 and out[31] >= 30 and out[32] >= 30 and out[63] >= 60
+
+
+def test_simd_kats(orc):
+    # simd.rs:1176-1198
+    assert abs(orc.dot_f32([1, 2, 3, 4, 5, 6, 7, 8], [1] * 8) - 36.0) < 1e-6
+    assert abs(orc.lib().orc_max_f32(np.array([1, 5, 3, 9, 2, 8, 4, 7, 6], np.float32).ctypes.data, 9) - 9.0) < 1e-6
+    s = orc.softmax([1.0, 2.0, 3.0, 4.0])
+    assert abs(s.sum() - 1.0) < 1e-6 and np.all(np.diff(s) > 0)       # ops.rs:1618-1632
+    assert np.allclose(orc.silu([0.0, 1.0, -1.0]), [0.0, 0.7310586, -0.26894143], atol=1e-6)
+
+
+def test_dot_f32_isa_variants_agree_to_rounding(orc):
+    rng = np.random.default_rng(7)
+    a, b = rng.standard_normal(4099).astype(np.float32), rng.standard_normal(4099).astype(np.float32)
+    ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    vals = []
+    for isa in (orc.ISA_SCALAR, orc.ISA_AVX2, orc.ISA_AVX512):
+        orc.set_isa(isa)
+        vals.append(orc.dot_f32(a, b))
+    orc.set_isa(orc.ISA_AUTO)
+    bound = 1e-5 * float(np.abs(a * b).sum())
+    assert all(abs(v - ref) < bound for v in vals)
+
+
+def test_greedy_and_argmax_rules(orc):
+    # sampling/mod.rs:442-453: greedy picks index 5
+    logits = [0.0, 0.1, 0.2, 0.3, 0.4, 1.0, 0.2, 0.1, 0.0, -0.1]
+    assert orc.greedy_sample(logits) == 5 and orc.argmax_last(logits) == 5
+    # Iterator::max_by returns the LAST maximum (main.rs:1815-1821)
+    assert orc.argmax_last([1.0, 3.0, 3.0, 2.0]) == 2
+
+
+def test_moe_router_kat(orc):
+    # moe.rs:505-517: zero router weights, hidden 0.1 -> 2 experts, weights sum to 1; stable sort keeps [0, 1]
+    idx, w = orc.moe_route(np.full(64, 0.1, np.float32), np.zeros((4, 64), np.float32), 4, 2, normalize=True)
+    assert idx.tolist() == [0, 1] and abs(w.sum() - 1.0) < 0.01
+
+
+def test_attention_gqa_smoke(orc):
+    # ops.rs:1780-1810 (shape / GQA head mapping / finiteness), through attention_cached
+    q = np.ones((4, 4), np.float32)
+    kc = np.ones((2, 1, 4), np.float32)
+    out = orc.attention_cached(q, kc, kc, 0.5, 1)
+    assert np.all(np.isfinite(out)) and np.allclose(out, 1.0)
+
+
+@pytest.mark.parametrize("tname", ["Q4_0", "Q8_0", "Q4_K", "Q5_K", "Q6_K", "Q8_K"])
+def test_fused_dot_equals_dequant_dot(orc, tname):
+    """Self-consistency identity for the dots the reference has no golden vector for."""
+    t = getattr(orc, tname)
+    rng = np.random.default_rng(hash(tname) % 2**32)
+    k = 2048
+    raw = orc.quantize(t, rng.standard_normal(k).astype(np.float32))
+    x = rng.standard_normal(k).astype(np.float32)
+    w = orc.dequantize(t, raw, k).astype(np.float64)
+    want = float(np.dot(w, x.astype(np.float64)))
+    got = orc.dot_q(t, raw, x)
+    assert abs(got - want) <= 1e-5 * float(np.abs(w * x).sum()) + 1e-6
+
+
+def test_vec_mat_q_matches_rowwise_dots_and_fallback(orc):
+    rng = np.random.default_rng(3)
+    k, n = 512, 6
+    x = rng.standard_normal(k).astype(np.float32)
+    for t in (orc.Q4_K, orc.Q6_K, orc.Q8_0, orc.Q5_0, orc.Q2_K):      # Q5_0 / Q2_K take the dequantize fallback
+        raw = orc.quantize(t, rng.standard_normal(k * n).astype(np.float32))
+        out = orc.vec_mat_q(t, raw, x, n)
+        rb = orc.nbytes_for(t, k)
+        for j in range(n):
+            row = raw[j * rb:(j + 1) * rb]
+            want = orc.dot_q(t, row, x) if orc.lib().orc_has_fused_dot(t) else orc.dot_f32(x, orc.dequantize(t, row, k))
+            assert out[j] == np.float32(want)
