@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/s of the MI355X engine on BASELINE.json's metric, with the roofline of the dominant
+kernel and the CPU baseline measured in the same run.
+
+    python bench.py --gpus 1 --steps 128 --warmup 8          (default: Llama-3-8B Q4_K_M, 128-token prompt)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   (layer pipeline)
+
+Protocol = the reference's `llama-gguf bench` (src/main.rs:1750-1871): prompt tokens i % 32000, prefill, then
+greedy decode feeding back the arg-max (last-max tie rule).  A "step" is one decoded token.  Weights are
+synthetic random-init blocks of the named architecture and quantization mix (no model files exist here);
+they are resident in HBM before the timed region and the token feedback stays on device
+(lgh_decode_greedy), so `value` contains no PCIe traffic; the PCIe-inclusive rate (full logits D2H per token,
+as GpuInference::forward returns them) is reported beside it as `pcie_inclusive_tokens_per_s`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="llama-3-8b")
+    ap.add_argument("--mix", default="Q4_K_M")
+    ap.add_argument("--prompt", type=int, default=128)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 disables)")
+    ap.add_argument("--profile-steps", type=int, default=16, help="steps of the eager hipEvent pass (0 disables)")
+    ap.add_argument("--attn-splits", type=int, default=0)
+    return ap.parse_args()
+
+
+def prompt_tokens(n: int, vocab: int):
+    return [(i % 32000) % vocab for i in range(n)]  # main.rs:1787
+
+
+def cpu_baseline(pkg, model, cfg, budget_s: float):
+    """The oracle (a C++ port of the reference CPU backend's arithmetic) timed on this host's cores, on a
+    bounded sample of the same workload: same weights, short prefill, a few decode tokens."""
+    orc = graft.load_oracle()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    orc.set_threads(cores)
+    ref = orc.Model(cfg.as_dict())
+    for name, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(name, t, ne, data)
+    ref.finalize()
+    pre = prompt_tokens(4, cfg.vocab_size)
+    t0 = time.perf_counter()
+    logits = ref.forward(pre)                      # also dequantizes the embedding table once
+    prefill_s = time.perf_counter() - t0
+    tok, n, t0 = orc.argmax_last(logits), 0, time.perf_counter()
+    while True:
+        logits = ref.forward([tok])
+        tok = orc.argmax_last(logits)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 32:
+            break
+    isa = {1: "scalar", 2: "avx2", 3: "avx512"}[orc.get_isa()]
+    ref.close()
+    return {"value": round(n / el, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} greedy decode tokens after a 4-token prefill ({prefill_s:.1f}s, untimed), same weights, "
+                      f"oracle C++ port of the reference CPU backend, kernel-only mode (embedding table dequantized "
+                      f"once, not per call), dot_f32 ISA path {isa}"}
+
+
+def run_single(args, pkg):
+    import torch
+    hb = pkg.hip_backend
+    if hb.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible (the engine has no CPU fallback)")
+    W, K, P = args.warmup, args.steps, args.profile_steps
+    max_seq = max(512, args.prompt + W + K + P + 16)
+    cfg = pkg.make_config(args.model, max_seq_len=max_seq)
+    want_cpu = args.cpu_seconds > 0
+    model = pkg.SynthModel(cfg, mix=args.mix)
+    t0 = time.perf_counter()
+    eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits)
+    load_s = time.perf_counter() - t0
+
+    prompt = prompt_tokens(args.prompt, cfg.vocab_size)
+    eng.forward_batch(prompt[:-1])
+    eng.forward(prompt[-1])                                           # prefill = Model::forward(prompt) (main.rs:1804-1807)
+    warm = eng.decode_greedy(prompt[-1], W) if W > 0 else np.array([prompt[-1]], np.uint32)  # main.rs:1812-1822
+    tok = int(warm[-1])
+    kv0 = eng.position()
+    # ---- timed region: exactly K decode steps, device-resident token feedback
+    torch.cuda.synchronize()
+    eng.synchronize()
+    t0 = time.perf_counter()
+    toks = eng.decode_greedy(tok, K)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kv1 = eng.position()
+    tok_s = K / elapsed
+    mean_kv = (kv0 + 1 + kv1) / 2.0
+    step_bytes = model.step_alg_bytes(int(round(mean_kv)))
+    # ---- PCIe-inclusive variant (GpuInference::forward returns all logits to the host)
+    orc_argmax = lambda v: int(len(v) - 1 - np.argmax(v[::-1]))      # last maximal index (main.rs:1815-1821)
+    n_pcie = min(K, 32)
+    eng.reset()
+    eng.forward_batch(prompt[:-1])
+    eng.forward(prompt[-1])
+    t0 = time.perf_counter()
+    t = prompt[-1]
+    for _ in range(n_pcie):
+        t = orc_argmax(eng.forward(t))
+    pcie_tok_s = n_pcie / (time.perf_counter() - t0)
+    # ---- roofline of the dominant kernel: eager pass with a hipEvent pair around every launch, on the launch stream
+    roofline = None
+    kernels = {}
+    if P > 0:
+        eng.set_profiling(True)
+        t = int(toks[-1])
+        for _ in range(P):
+            t = eng.forward_argmax(t)
+        eng.set_profiling(False)
+        st = eng.stats()
+        syms = st["symbols"]
+        dom = max(syms, key=lambda s: syms[s]["time_us"])
+        d = syms[dom]
+        avg_us = d["time_us"] / d["launches"]
+        bytes_per_launch = d["alg_bytes"] / d["launches"]
+        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "launches_per_step": d["launches"] / P, "avg_launch_us": round(avg_us, 3),
+                    "alg_bytes_per_launch": int(bytes_per_launch)}
+        tot = sum(v["time_us"] for v in syms.values())
+        kernels = {s: {"launches_per_step": v["launches"] / P, "avg_us": round(v["time_us"] / v["launches"], 3),
+                       "share": round(v["time_us"] / tot, 4),
+                       "GBps": round(v["alg_bytes"] / max(v["time_us"], 1e-9) / 1e3, 1)} for s, v in syms.items()}
+        kernels["_classes"] = {k: {"launches_per_step": v["launches"] / P, "avg_us": round(v["time_us"] / v["launches"], 3)}
+                               for k, v in st["kernels"].items()}
+    stats = eng.stats()
+    eng.close()
+    cpu = cpu_baseline(pkg, model, cfg, args.cpu_seconds) if want_cpu else None
+    out = {
+        "metric": "decode tokens/sec Llama-3-8B Q4_K_M, 1 GPU; % of HBM roofline" if (args.model, args.mix) == ("llama-3-8b", "Q4_K_M")
+                  else f"decode tokens/sec {args.model} {args.mix}, 1 GPU; % of HBM roofline",
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, seq_len=1, {args.prompt}-token prompt "
+                               f"prefilled, kv_len {kv0 + 1}..{kv1}", "quant_mix": args.mix, "prompt_tokens": args.prompt,
+                   "parallelism": "single GPU", "weights": "random-init synthetic blocks (SURVEY.md §8d)"},
+        "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
+                         "peak_GBps": HBM_PEAK_GBPS, "frac": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
+        "roofline": roofline, "cpu_baseline": cpu,
+        "pcie_inclusive_tokens_per_s": round(pcie_tok_s, 2),
+        "graph_nodes_per_token": stats["graph_nodes"], "weight_bytes_resident": stats["weight_bytes"],
+        "load_seconds": round(load_s, 1), "kernels": kernels,
+    }
+    print(json.dumps(out))
+
+
+class _Keep:
+    """Makes from_model keep the generated payloads so the CPU baseline reuses the same bytes."""
+
+    def __init__(self, model):
+        self._m, self.config = model, model.config
+
+    def tensors(self, layers=None):
+        return self._m.tensors(layers, keep=True)
+
+
+def run_pipeline(args, pkg):
+    """N > 1: layers pipeline-sharded over N GPUs, one process per GPU, hidden vector hopped with RCCL send/recv."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev)
+    W, K = args.warmup, args.steps
+    max_seq = max(512, args.prompt + W + K + 16)
+    cfg = pkg.make_config(args.model, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=args.mix)
+    lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
+    eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits)
+    stage = pkg.pipeline.HipStage(eng, torch, dev)
+    dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
+    prompt = prompt_tokens(args.prompt, cfg.vocab_size)
+    for t in prompt:                                   # token-by-token prefill through the pipeline
+        dec.step(t)
+    tok = prompt[-1]
+    for _ in range(W):
+        tok = dec.step(tok)
+    kv0 = eng.position()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        tok = dec.step(tok)
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kv1 = eng.position()
+    if rank == 0:
+        tok_s = K / elapsed
+        step_bytes = model.step_alg_bytes(int(round((kv0 + 1 + kv1) / 2)))
+        print(json.dumps({
+            "metric": f"decode tokens/sec {args.model} {args.mix}, {world} GPUs (layer pipeline); % of HBM roofline",
+            "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, kv_len {kv0 + 1}..{kv1}",
+                       "parallelism": f"pp{world} (contiguous layer ranges, f32[hidden] hop per stage over RCCL send/recv)",
+                       "prompt_tokens": args.prompt},
+            "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
+                             "peak_GBps_one_gpu": HBM_PEAK_GBPS, "frac_of_one_gpu": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
+            "roofline": None, "cpu_baseline": None,
+        }))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    pkg = graft.load_package()
+    from importlib import import_module
+    pkg.pipeline = import_module("llama_gguf_amd.pipeline")
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        run_pipeline(args, pkg)
+    else:
+        run_single(args, pkg)
+
+
+if __name__ == "__main__":
+    main()

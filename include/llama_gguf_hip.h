@@ -97,6 +97,27 @@ enum {
   LGH_K_DOWN = 6, LGH_K_ROUTER = 7, LGH_K_OUTPUT = 8, LGH_K_ARGMAX = 9, LGH_K_MISC = 10, LGH_K_COUNT = 16
 };
 
+/* kernel SYMBOLS reported by lgh_get_stats (profiling mode): what `rocprofv3 --kernel-trace --stats` groups by.
+ * LGH_SYM_MV_* are the instantiations of lgh::mv_kernel<MASK, MAXT> (the fused dequant mat-vec). */
+enum {
+  LGH_SYM_MV_Q4K = 0,      /* lgh::mv_kernel<1u, 1024>  : every launch whose matrices are all Q4_K */
+  LGH_SYM_MV_Q80 = 1,      /* lgh::mv_kernel<8u, 1024> */
+  LGH_SYM_MV_Q40 = 2,      /* lgh::mv_kernel<16u, 1024> */
+  LGH_SYM_MV_Q5K = 3,      /* lgh::mv_kernel<2u, 512> */
+  LGH_SYM_MV_Q6K = 4,      /* lgh::mv_kernel<4u, 512> */
+  LGH_SYM_MV_Q4K_Q6K = 5,  /* lgh::mv_kernel<5u, 512>   : mixed-type QKV launches */
+  LGH_SYM_MV_Q5K_Q6K = 6,  /* lgh::mv_kernel<6u, 512> */
+  LGH_SYM_MV_ALL = 7,      /* lgh::mv_kernel<31u, 512> */
+  LGH_SYM_F32_MATVEC = 8,  /* lgh::f32_matvec_kernel */
+  LGH_SYM_ATTN = 9,        /* lgh::attn_partial_kernel<D, G> */
+  LGH_SYM_ATTN_COMBINE = 10,
+  LGH_SYM_EMBED = 11,
+  LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
+  LGH_SYM_ROUTER = 13,
+  LGH_SYM_OTHER = 14,
+  LGH_SYM_COUNT = 16
+};
+
 typedef struct lgh_stats {
   uint64_t weight_bytes;             /* quantized + f32 weight bytes resident in HBM */
   uint64_t kv_bytes;                 /* KV cache bytes */
@@ -107,6 +128,10 @@ typedef struct lgh_stats {
   uint64_t k_launches[LGH_K_COUNT];
   double k_time_us[LGH_K_COUNT];
   uint64_t k_alg_bytes[LGH_K_COUNT];
+  /* the same, grouped by kernel symbol (LGH_SYM_*) */
+  uint64_t sym_launches[LGH_SYM_COUNT];
+  double sym_time_us[LGH_SYM_COUNT];
+  uint64_t sym_alg_bytes[LGH_SYM_COUNT];
   /* algorithmic bytes of one decode step at the current position (SURVEY.md §8d formula) */
   uint64_t step_alg_bytes;
 } lgh_stats;
@@ -197,9 +222,10 @@ int lgh_op_swiglu_vec_mat(int device, uint32_t ggml_type, const void* w_gate, co
 
 /* Micro-benchmark of the fused quantized mat-vec kernel on device-resident synthetic data:
  * `iters` back-to-back launches timed with hipEvents on the launch stream.  mode 0 = plain matvec,
- * 1 = rmsnorm prologue, 2 = gate/up SwiGLU pair.  avg_us = mean device time per launch. */
+ * 1 = rmsnorm prologue, 2 = gate/up SwiGLU pair.  `copies` device copies of the weights are cycled so the
+ * 256 MiB Infinity Cache does not serve re-reads.  avg_us = mean device time per launch. */
 int lgh_bench_vec_mat(int device, uint32_t ggml_type, const void* w, const void* w2, size_t k, size_t n, int mode,
-                      int iters, double* avg_us);
+                      int iters, int copies, double* avg_us);
 
 #ifdef __cplusplus
 }

@@ -117,22 +117,32 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
   }
 }
 
-// out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}
+// out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}.  Lane s of the first wave owns split s
+// (all loads of a phase are independent and in flight together: the kernel is two memory round trips long).
 __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
                                                            uint32_t g_per_kv, uint32_t head_dim, uint32_t n_splits,
                                                            float* __restrict__ out) {
+  __shared__ float s_f[64];
+  __shared__ float s_linv;
   const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
-  float mn = kNegBig;
-  for (uint32_t s = 0; s < n_splits; s++) mn = fmaxf(mn, part_ml[(((size_t)kvh * n_splits + s) * g_per_kv + g) * 2]);
+  const size_t p0 = (size_t)kvh * n_splits * g_per_kv + g;   // split s lives at p0 + s * g_per_kv
+  if (threadIdx.x < 64) {
+    const uint32_t s = threadIdx.x;
+    const bool ok = s < n_splits;
+    const float m = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2] : kNegBig;
+    const float l = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2 + 1] : 0.0f;
+    const float mn = wave_max(m);
+    const float f = expf(m - mn);
+    const float lsum = wave_sum(l * f);
+    s_f[s] = f;
+    if (s == 0) s_linv = 1.0f / lsum;  // simd.rs:718-720: multiply by 1/sum
+  }
+  __syncthreads();
   for (uint32_t dim = threadIdx.x; dim < head_dim; dim += blockDim.x) {
-    float lsum = 0.0f, a = 0.0f;
-    for (uint32_t s = 0; s < n_splits; s++) {
-      const size_t pi = ((size_t)kvh * n_splits + s) * g_per_kv + g;
-      const float f = expf(part_ml[pi * 2] - mn);
-      lsum += part_ml[pi * 2 + 1] * f;
-      a += part_acc[pi * head_dim + dim] * f;
-    }
-    out[(size_t)h * head_dim + dim] = a * (1.0f / lsum);  // simd.rs:718-720: multiply by 1/sum
+    float a = 0.0f;
+#pragma unroll 8
+    for (uint32_t s = 0; s < n_splits; s++) a += part_acc[(p0 + (size_t)s * g_per_kv) * head_dim + dim] * s_f[s];
+    out[(size_t)h * head_dim + dim] = a * s_linv;
   }
 }
 

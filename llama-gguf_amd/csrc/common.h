@@ -134,8 +134,9 @@ struct MvPlan {               // geometry chosen by the host for one weight shap
 };
 
 // matvec
-hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan);
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
 hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
+int mv_symbol(const MvLaunch& L);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
 hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
                              float eps, const float* resid, hipStream_t st);
 

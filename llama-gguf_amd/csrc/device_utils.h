@@ -40,10 +40,34 @@ __device__ __forceinline__ float fma4(uint32_t v, const float* x, float acc) {
   return acc;
 }
 
+// Makes `v` opaque to the optimizer at this point (no instruction is emitted).  Used after nibble masks so
+// that `(m >> 8) & 0xFF` stays a single v_cvt_f32_ubyte1 instead of being re-folded into v_bfe_u32 + cvt.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+  asm("" : "+v"(v));
+  return v;
+}
+
 // full-wave (64 lanes) sum; every lane gets the result; fixed order -> deterministic
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// DPP lane permutation of a float (gfx9 DPP controls): no LDS crossbar, full-rate VALU
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+
+// 64-lane sum by DPP; the total is valid in LANE 63 only.  Fixed order -> deterministic.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);       // row_half_mirror
+  v += dpp_f<0x140>(v);       // row_mirror  -> every lane of a 16-lane row holds the row sum
+  v += dpp_f<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+  v += dpp_f<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
   return v;
 }
 

@@ -23,7 +23,7 @@ struct LayerW {
 
 enum TokenMode { MODE_PREFILL = 0, MODE_FORWARD = 1, MODE_GREEDY = 2, MODE_COUNT = 3 };
 
-struct ProfRec { int cls; hipEvent_t a, b; };
+struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
 }  // namespace lgh
 
@@ -99,8 +99,8 @@ int drain_prof(lgh_ctx* c);
 // launch recording (profiling mode: hipEvent pair per launch, on the launch stream)
 // ------------------------------------------------------------------------------------------------
 template <class F>
-inline int run_k(lgh_ctx* c, int cls, uint64_t alg_bytes, F&& f) {
-  lgh::ProfRec rec{cls, nullptr, nullptr};
+inline int run_k(lgh_ctx* c, int cls, int sym, uint64_t alg_bytes, F&& f) {
+  lgh::ProfRec rec{cls, sym, alg_bytes, nullptr, nullptr};
   if (c->profiling) {
     if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return fail(c, LGH_OPERATION_FAILED, "hipEventCreate");
     (void)hipEventRecord(rec.a, c->stream);
@@ -110,7 +110,6 @@ inline int run_k(lgh_ctx* c, int cls, uint64_t alg_bytes, F&& f) {
   if (c->profiling) {
     (void)hipEventRecord(rec.b, c->stream);
     c->prof.push_back(rec);
-    c->stats.k_alg_bytes[cls] += alg_bytes;
   }
   return LGH_OK;
 }

@@ -166,6 +166,10 @@ int drain_prof(lgh_ctx* c) {
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       c->stats.k_time_us[r.cls] += (double)ms * 1000.0;
       c->stats.k_launches[r.cls] += 1;
+      c->stats.k_alg_bytes[r.cls] += r.bytes;
+      c->stats.sym_time_us[r.sym] += (double)ms * 1000.0;
+      c->stats.sym_launches[r.sym] += 1;
+      c->stats.sym_alg_bytes[r.sym] += r.bytes;
     }
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
@@ -187,13 +191,14 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
   L.norm_w = norm_w;
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
-  uint32_t wg = 0, threads = 0;
+  uint32_t wg = 0, threads = 0, launch_rows = 0;
   uint64_t alg = 0;
+  for (int s = 0; s < nseg; s++) launch_rows += specs[s].W[0]->n;
   for (int s = 0; s < nseg; s++) {
     const SegSpec& sp = specs[s];
     const DevWeight& W0 = *sp.W[0];
     MvPlan plan;
-    if (mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan) != hipSuccess)
+    if (mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan, launch_rows) != hipSuccess)
       return fail(c, LGH_UNSUPPORTED, "no fused mat-vec plan for type " + std::to_string(W0.type) + " k=" + std::to_string(W0.k));
     MvSeg& S = L.seg[s];
     S.type = W0.type;
@@ -219,7 +224,7 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
     if (plan.threads > threads) threads = plan.threads;
   }
   alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
-  return run_k(c, cls, alg, [&] { return mv_launch(L, wg, threads, c->stream); });
+  return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
 }
 
 // one Linear with optional norm prologue / residual epilogue, any device type
@@ -233,7 +238,7 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
     return launch_mv(c, cls, &sp, 1, norm_w, W.k);
   }
   if (bias) return fail(c, LGH_UNSUPPORTED, "bias on a non-quantized linear layer is not supported");
-  return run_k(c, cls, (uint64_t)W.n * W.k * 4, [&] {
+  return run_k(c, cls, LGH_SYM_F32_MATVEC, (uint64_t)W.n * W.k * 4, [&] {
     return f32_matvec_launch((const float*)W.plane[0], x, out, W.k, W.n, norm_w, c->d.norm_eps, resid, c->stream);
   });
 }
@@ -260,11 +265,11 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wq, c->hidden, c->q, Lw.attn_norm, nullptr, Lw.bq))) return rc;
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wk, c->hidden, kt, Lw.attn_norm, nullptr, Lw.bk))) return rc;
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wv, c->hidden, vt, Lw.attn_norm, nullptr, Lw.bv))) return rc;
-    if ((rc = run_k(c, LGH_K_MISC, 0, [&] {
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] {
            return rope_launch(c->q, kt, d.num_heads, d.num_kv_heads, d.head_dim, c->state + ST_POS, c->rope_cs, (int)d.use_neox_rope, c->stream);
          })))
       return rc;
-    if ((rc = run_k(c, LGH_K_MISC, 0, [&] {
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] {
            return kv_store_launch(kt, vt, Lw.kcache, Lw.vcache, d.num_kv_heads, d.head_dim, d.max_seq_len, c->state + ST_POS, c->stream);
          })))
       return rc;
@@ -272,12 +277,12 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
   // ---- attention_cached (ops.rs:1479-1537)
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
-  if ((rc = run_k(c, LGH_K_ATTN, kv_bytes, [&] {
+  if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
          return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
                             c->state + ST_POS, 0, c->n_splits, c->part_ml, c->part_acc, c->stream);
        })))
     return rc;
-  if ((rc = run_k(c, LGH_K_ATTN_COMBINE, 0, [&] {
+  if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
          return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out, c->stream);
        })))
     return rc;
@@ -296,13 +301,13 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
     } else {
       if ((rc = linear_any(c, LGH_K_GATEUP, Lw.gate, c->hidden, c->act, Lw.ffn_norm, nullptr, nullptr))) return rc;
       if ((rc = linear_any(c, LGH_K_GATEUP, Lw.up, c->hidden, c->act2, Lw.ffn_norm, nullptr, nullptr))) return rc;
-      if ((rc = run_k(c, LGH_K_MISC, 0, [&] { return silu_mul_launch(c->act, c->act2, c->act, Lw.gate.n, c->stream); }))) return rc;
+      if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return silu_mul_launch(c->act, c->act2, c->act, Lw.gate.n, c->stream); }))) return rc;
     }
     return linear_any(c, LGH_K_DOWN, Lw.down, c->act, c->hidden, nullptr, c->hidden, nullptr);
   }
   // ---- MoE (moe.rs:321-413): router + top-k on device, experts selected by device-side index
   const uint32_t topk = d.num_experts_per_token;
-  if ((rc = run_k(c, LGH_K_ROUTER, (uint64_t)d.num_experts * H * 4, [&] {
+  if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)d.num_experts * H * 4, [&] {
          return moe_router_launch(c->hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, d.num_experts, topk, c->moe_sel, c->moe_w, c->stream);
        })))
     return rc;
@@ -340,12 +345,12 @@ static int enqueue_token(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   int rc;
   if (c->first) {
-    if ((rc = run_k(c, LGH_K_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
+    if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
            return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, c->stream);
          })))
       return rc;
   } else {
-    if ((rc = run_k(c, LGH_K_MISC, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
   }
   for (uint32_t li = c->l0; li < c->l1; li++)
     if ((rc = layer_forward(c, li))) return rc;
@@ -353,7 +358,7 @@ static int enqueue_token(lgh_ctx* c, int mode) {
     // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
     if ((rc = linear_any(c, LGH_K_OUTPUT, c->output, c->hidden, c->logits, c->output_norm, nullptr, nullptr))) return rc;
     if (mode == MODE_GREEDY) {
-      if ((rc = run_k(c, LGH_K_ARGMAX, (uint64_t)d.vocab_size * 4, [&] {
+      if ((rc = run_k(c, LGH_K_ARGMAX, LGH_SYM_ARGMAX, (uint64_t)d.vocab_size * 4, [&] {
              return argmax_launch(c->logits, d.vocab_size, c->amax_v, c->amax_i, c->state, c->tok_log, c->stream);
            })))
         return rc;
@@ -756,6 +761,9 @@ int lgh_set_profiling(lgh_ctx* c, int on) {
     std::memset(c->stats.k_launches, 0, sizeof(c->stats.k_launches));
     std::memset(c->stats.k_time_us, 0, sizeof(c->stats.k_time_us));
     std::memset(c->stats.k_alg_bytes, 0, sizeof(c->stats.k_alg_bytes));
+    std::memset(c->stats.sym_launches, 0, sizeof(c->stats.sym_launches));
+    std::memset(c->stats.sym_time_us, 0, sizeof(c->stats.sym_time_us));
+    std::memset(c->stats.sym_alg_bytes, 0, sizeof(c->stats.sym_alg_bytes));
   }
   return LGH_OK;
 }

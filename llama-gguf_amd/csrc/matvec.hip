@@ -21,19 +21,61 @@
 
 namespace lgh {
 
+// Diagnostic build only (-DLGH_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at phase
+// boundaries into a buffer nothing else reads; lgh_bench_vec_mat prints the phase profile.  Never in the product .so.
+#ifdef LGH_STAMPS
+__device__ unsigned long long g_stamps[8192 * 8];
+#define LGH_STAMP(i)                                                                             \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+hipError_t mv_read_stamps(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long));
+}
+#else
+#define LGH_STAMP(i)
+#endif
+
 enum : uint32_t { M_Q4K = 1, M_Q5K = 2, M_Q6K = 4, M_Q80 = 8, M_Q40 = 16, M_ALL = 31 };
 
-__device__ __forceinline__ void load_run16(float* dst, const float* x, const float* nw, float inv, bool do_norm) {
+// x runs of 16 consecutive floats into registers.  With the RMSNorm prologue the registers hold x*w (the norm
+// weight) and `ss` accumulates sum(x^2) of the raw values: the mat-vec is linear in x, so the 1/rms factor
+// is applied once per output row in the epilogue instead of per element before the dot — the reduction over
+// all of x then overlaps the weight stream instead of preceding it.
+// ALL loads of all runs are issued before any value is used (a branch between loads would make hipcc wait
+// for each one in turn: measured 4 us of serialized L2 round trips).
+template <int NRUN>
+__device__ __forceinline__ void load_runs(float (*dst)[16], const float* const* xp, const float* const* wp, float& ss,
+                                          bool do_norm) {
+  f32x4 xv[NRUN][4], wv[NRUN][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
-    if (do_norm) {
-      f32x4 w = *reinterpret_cast<const f32x4*>(nw + 4 * i);
-      // (x * inv_rms) * w : two roundings, as simd.rs:891-892
-      v = (v * inv) * w;
-    }
-    dst[4 * i + 0] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+  for (int r = 0; r < NRUN; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) xv[r][i] = *reinterpret_cast<const f32x4*>(xp[r] + 4 * i);
+  if (do_norm) {
+#pragma unroll
+    for (int r = 0; r < NRUN; r++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) wv[r][i] = *reinterpret_cast<const f32x4*>(wp[r] + 4 * i);
+#pragma unroll
+    for (int r = 0; r < NRUN; r++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        f32x4 v = xv[r][i];
+        ss = __builtin_fmaf(v.x, v.x, ss);
+        ss = __builtin_fmaf(v.y, v.y, ss);
+        ss = __builtin_fmaf(v.z, v.z, ss);
+        ss = __builtin_fmaf(v.w, v.w, ss);
+        xv[r][i] = v * wv[r][i];
+      }
   }
+#pragma unroll
+  for (int r = 0; r < NRUN; r++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      dst[r][4 * i + 0] = xv[r][i].x; dst[r][4 * i + 1] = xv[r][i].y;
+      dst[r][4 * i + 2] = xv[r][i].z; dst[r][4 * i + 3] = xv[r][i].w;
+    }
 }
 
 __device__ __forceinline__ float sum16(const float* v) {
@@ -48,18 +90,19 @@ __device__ __forceinline__ float sum16(const float* v) {
 // qs[32p+16h .. +16) hold elements 64p+16h+j (low nibbles, sub-block 2p) and 64p+32+16h+j (high
 // nibbles, sub-block 2p+1)   — layout of dequant.rs:232-255.
 struct FmtQ4K {
-  static constexpr int B = 8;
+  static constexpr int B = 3;
   static constexpr uint32_t UNIT = 32;
-  struct X { float lo[16], hi[16]; float slo, shi; uint32_t sh; uint32_t upper; };
+  struct X { float v[2][16]; float slo, shi; uint32_t sh; uint32_t upper; };  // v[0] low-nibble run, v[1] high
   struct Raw { u32x4 hd, qs; };
 
-  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float& ss, bool nrm, uint32_t u) {
     uint32_t p = (u >> 1) & 3;
     uint32_t e0 = (u >> 3) * 256 + p * 64 + (u & 1) * 16;
-    load_run16(X_.lo, x + e0, nw + e0, inv, nrm);
-    load_run16(X_.hi, x + e0 + 32, nw + e0 + 32, inv, nrm);
-    X_.slo = sum16(X_.lo);
-    X_.shi = sum16(X_.hi);
+    const float* xp[2] = {x + e0, x + e0 + 32};
+    const float* wp[2] = {nw + e0, nw + e0 + 32};
+    load_runs<2>(X_.v, xp, wp, ss, nrm);
+    X_.slo = sum16(X_.v[0]);
+    X_.shi = sum16(X_.v[1]);
     X_.sh = (p & 1) * 16;
     X_.upper = p >> 1;
   }
@@ -84,8 +127,8 @@ struct FmtQ4K {
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t v = r.qs[w];
-      alo = fma4(v & 0x0F0F0F0Fu, X_.lo + 4 * w, alo);
-      ahi = fma4((v >> 4) & 0x0F0F0F0Fu, X_.hi + 4 * w, ahi);
+      alo = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, alo);
+      ahi = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ahi);
     }
     float sc_lo, sc_hi, m_lo, m_hi;
     scales(r.hd, X_, sc_lo, sc_hi, m_lo, m_hi);
@@ -98,18 +141,19 @@ struct FmtQ4K {
 // as Q4_K plus qh[32]: bit 2p of qh[16h+j] is the 5th bit of the low-nibble element, bit 2p+1 of the
 // high-nibble element (dequant.rs:287-315).
 struct FmtQ5K {
-  static constexpr int B = 6;
+  static constexpr int B = 3;
   static constexpr uint32_t UNIT = 32;
-  struct X { float lo[16], hi[16]; float slo, shi; uint32_t sh; uint32_t upper; uint32_t qsh; };
+  struct X { float v[2][16]; float slo, shi; uint32_t sh; uint32_t upper; uint32_t qsh; };
   struct Raw { u32x4 hd, qh, qs; };
 
-  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float& ss, bool nrm, uint32_t u) {
     uint32_t p = (u >> 1) & 3;
     uint32_t e0 = (u >> 3) * 256 + p * 64 + (u & 1) * 16;
-    load_run16(X_.lo, x + e0, nw + e0, inv, nrm);
-    load_run16(X_.hi, x + e0 + 32, nw + e0 + 32, inv, nrm);
-    X_.slo = sum16(X_.lo);
-    X_.shi = sum16(X_.hi);
+    const float* xp[2] = {x + e0, x + e0 + 32};
+    const float* wp[2] = {nw + e0, nw + e0 + 32};
+    load_runs<2>(X_.v, xp, wp, ss, nrm);
+    X_.slo = sum16(X_.v[0]);
+    X_.shi = sum16(X_.v[1]);
     X_.sh = (p & 1) * 16;
     X_.upper = p >> 1;
     X_.qsh = 2 * p;
@@ -127,8 +171,8 @@ struct FmtQ5K {
       uint32_t v = r.qs[w], t = r.qh[w] >> X_.qsh;
       uint32_t qlo = (v & 0x0F0F0F0Fu) | ((t << 4) & 0x10101010u);
       uint32_t qhi = ((v >> 4) & 0x0F0F0F0Fu) | ((t << 3) & 0x10101010u);
-      alo = fma4(qlo, X_.lo + 4 * w, alo);
-      ahi = fma4(qhi, X_.hi + 4 * w, ahi);
+      alo = fma4(opaque(qlo), X_.v[0] + 4 * w, alo);
+      ahi = fma4(opaque(qhi), X_.v[1] + 4 * w, ahi);
     }
     float sc_lo, sc_hi, m_lo, m_hi;
     FmtQ4K::X sx;  // reuse the Q4_K scale unpack (same 12-byte packing)
@@ -145,18 +189,18 @@ struct FmtQ5K {
 // nibble from ql[64n+32(t&1)+l] (high nibble for t>=2) and bits 2t..2t+1 of qh[32n+l]; scale index
 // 8n+c+2t  (dequant.rs:321-356).  q-32 is folded in as  sum(q*x) - 32*sum(x).
 struct FmtQ6K {
-  static constexpr int B = 4;
+  static constexpr int B = 2;
   static constexpr uint32_t UNIT = 64;
   struct X { float q[4][16]; float s[4]; uint32_t shc; };
   struct Raw { u32x4 qa, qb, qh; u32x2 sc; uint32_t d; };
 
-  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float& ss, bool nrm, uint32_t u) {
     uint32_t e0 = (u >> 2) * 256 + ((u >> 1) & 1) * 128 + (u & 1) * 16;
+    const float* xp[4] = {x + e0, x + e0 + 32, x + e0 + 64, x + e0 + 96};
+    const float* wp[4] = {nw + e0, nw + e0 + 32, nw + e0 + 64, nw + e0 + 96};
+    load_runs<4>(X_.q, xp, wp, ss, nrm);
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      load_run16(X_.q[t], x + e0 + 32 * t, nw + e0 + 32 * t, inv, nrm);
-      X_.s[t] = sum16(X_.q[t]);
-    }
+    for (int t = 0; t < 4; t++) X_.s[t] = sum16(X_.q[t]);
     X_.shc = (u & 1) * 8;
   }
   static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
@@ -178,10 +222,10 @@ struct FmtQ6K {
       uint32_t v1 = (b & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
       uint32_t v2 = ((a >> 4) & 0x0F0F0F0Fu) | (h & 0x30303030u);
       uint32_t v3 = ((b >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
-      a0 = fma4(v0, X_.q[0] + 4 * w, a0);
-      a1 = fma4(v1, X_.q[1] + 4 * w, a1);
-      a2 = fma4(v2, X_.q[2] + 4 * w, a2);
-      a3 = fma4(v3, X_.q[3] + 4 * w, a3);
+      a0 = fma4(opaque(v0), X_.q[0] + 4 * w, a0);
+      a1 = fma4(opaque(v1), X_.q[1] + 4 * w, a1);
+      a2 = fma4(opaque(v2), X_.q[2] + 4 * w, a2);
+      a3 = fma4(opaque(v3), X_.q[3] + 4 * w, a3);
     }
     uint64_t sv = (((uint64_t)r.sc.y << 32) | r.sc.x) >> X_.shc;
     float s0 = (float)(int)(int8_t)(sv), s1 = (float)(int)(int8_t)(sv >> 16);
@@ -198,15 +242,16 @@ struct FmtQ6K {
 // planes: qs[32] (i8), d per block; unit = one block.  q is read as q+128 (sign bit flipped) so the
 // unsigned byte->f32 convert applies:  sum(q*x) = sum((q^0x80)*x) - 128*sum(x).
 struct FmtQ80 {
-  static constexpr int B = 6;
+  static constexpr int B = 3;
   static constexpr uint32_t UNIT = 32;
-  struct X { float v[32]; float s; };
+  struct X { float v[2][16]; float s; };
   struct Raw { u32x4 q0, q1; uint32_t d; };
 
-  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
-    load_run16(X_.v, x + u * 32, nw + u * 32, inv, nrm);
-    load_run16(X_.v + 16, x + u * 32 + 16, nw + u * 32 + 16, inv, nrm);
-    X_.s = sum16(X_.v) + sum16(X_.v + 16);
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float& ss, bool nrm, uint32_t u) {
+    const float* xp[2] = {x + u * 32, x + u * 32 + 16};
+    const float* wp[2] = {nw + u * 32, nw + u * 32 + 16};
+    load_runs<2>(X_.v, xp, wp, ss, nrm);
+    X_.s = sum16(X_.v[0]) + sum16(X_.v[1]);
   }
   static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
     size_t blk = (size_t)row * nblk + u;
@@ -217,9 +262,9 @@ struct FmtQ80 {
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
     float a = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) a = fma4(r.q0[w] ^ 0x80808080u, X_.v + 4 * w, a);
+    for (int w = 0; w < 4; w++) a = fma4(opaque(r.q0[w] ^ 0x80808080u), X_.v[0] + 4 * w, a);
 #pragma unroll
-    for (int w = 0; w < 4; w++) a = fma4(r.q1[w] ^ 0x80808080u, X_.v + 16 + 4 * w, a);
+    for (int w = 0; w < 4; w++) a = fma4(opaque(r.q1[w] ^ 0x80808080u), X_.v[1] + 4 * w, a);
     return h2f(r.d) * __builtin_fmaf(-128.0f, X_.s, a);
   }
 };
@@ -228,15 +273,16 @@ struct FmtQ80 {
 // planes: qs[16], d per block; unit = one block: low nibble j -> element j, high nibble -> 16+j
 // (dequant.rs:16-30);  (q-8) folded in as sum(q*x) - 8*sum(x).
 struct FmtQ40 {
-  static constexpr int B = 8;
+  static constexpr int B = 3;
   static constexpr uint32_t UNIT = 32;
-  struct X { float lo[16], hi[16]; float s; };
+  struct X { float v[2][16]; float s; };
   struct Raw { u32x4 qs; uint32_t d; };
 
-  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float inv, bool nrm, uint32_t u) {
-    load_run16(X_.lo, x + u * 32, nw + u * 32, inv, nrm);
-    load_run16(X_.hi, x + u * 32 + 16, nw + u * 32 + 16, inv, nrm);
-    X_.s = sum16(X_.lo) + sum16(X_.hi);
+  static __device__ __forceinline__ void load_x(X& X_, const float* x, const float* nw, float& ss, bool nrm, uint32_t u) {
+    const float* xp[2] = {x + u * 32, x + u * 32 + 16};
+    const float* wp[2] = {nw + u * 32, nw + u * 32 + 16};
+    load_runs<2>(X_.v, xp, wp, ss, nrm);
+    X_.s = sum16(X_.v[0]) + sum16(X_.v[1]);
   }
   static __device__ __forceinline__ void load(Raw& r, const uint8_t* const* pl, uint32_t row, uint32_t nblk, uint32_t u) {
     size_t blk = (size_t)row * nblk + u;
@@ -248,8 +294,8 @@ struct FmtQ40 {
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t v = r.qs[w];
-      alo = fma4(v & 0x0F0F0F0Fu, X_.lo + 4 * w, alo);
-      ahi = fma4((v >> 4) & 0x0F0F0F0Fu, X_.hi + 4 * w, ahi);
+      alo = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, alo);
+      ahi = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ahi);
     }
     return h2f(r.d) * __builtin_fmaf(-8.0f, X_.s, alo + ahi);
   }
@@ -258,7 +304,7 @@ struct FmtQ40 {
 // ------------------------------------------------------------------------------------------ body
 constexpr int kRedFloats = 4096;
 
-// 1/rms of x over the whole workgroup; identical in every workgroup (fixed reduction order)
+// block-wide variant for the f32 kernel
 __device__ __forceinline__ float block_inv_rms(const float* x, uint32_t k, float eps, float* wsum) {
   const uint32_t tid = threadIdx.x, nthr = blockDim.x;
   float ss = 0.0f;
@@ -275,14 +321,20 @@ __device__ __forceinline__ float block_inv_rms(const float* x, uint32_t k, float
   float tot = 0.0f;
   const uint32_t nw = nthr >> 6;
   for (uint32_t w = 0; w < nw; w++) tot += wsum[w];
-  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
   float rms = __builtin_sqrtf(tot / (float)k + eps);
   return 1.0f / rms;
 }
 
+// The streaming loop of one wave.  Work items = (pass, batch of F::B rows), flattened so the pipeline runs
+// across passes (gate -> up).  Two register buffers alternate: the loads of item i+1 are in flight while
+// item i is being reduced, and the very first loads are issued before x is even read.  Every load of an item
+// is unconditional (out-of-range rows are clamped onto the last valid one) so that hipcc can count the
+// outstanding loads statically and emit partial `s_waitcnt vmcnt(N)` instead of draining the next batch.
 template <class F>
-__device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint32_t wg, float inv, float* red) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint32_t wg, float* red, float* ssq) {
+  const uint32_t lane = threadIdx.x & 63;
+  // wave-uniform bookkeeping lives in SGPRs (readfirstlane): no vector divides, no exec-masked branches
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wave >= S.T * S.G) return;
   const uint32_t ks = wave % S.T, rg = wave / S.T;
   const uint32_t u = ks * 64 + lane;
@@ -291,47 +343,93 @@ __device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint3
   const uint32_t rpg = S.rows_per_wg / S.G;
   const uint32_t row0 = wg * S.rows_per_wg + rg * rpg;
   const bool nrm = L.do_norm != 0;
-  typename F::X X_;
-  for (int p = 0; p < S.npass; p++) {
+  const bool has_rows = row0 < S.n_rows;
+  const uint32_t rows_here = has_rows ? min(rpg, S.n_rows - row0) : 0;
+  const uint32_t nb = (rows_here + F::B - 1) / F::B;
+  const uint32_t rbase = has_rows ? row0 : 0;
+
+  auto issue = [&](uint32_t p, uint32_t j, typename F::Raw* buf) {
     const MvPass& P = S.pass[p];
-    if (p == 0 || P.x != S.pass[p - 1].x) F::load_x(X_, P.x, L.norm_w, inv, nrm, uc);
+    const uint64_t e = P.sel ? (uint64_t)(uint32_t)(*P.sel) : 0;
     const uint8_t* pl[4];
-    {
-      uint64_t e = P.sel ? (uint64_t)(uint32_t)(*P.sel) : 0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) pl[i] = P.plane[i] + e * P.sel_stride[i];
-    }
+    for (int i = 0; i < 4; i++) pl[i] = P.plane[i] + e * P.sel_stride[i];
+#pragma unroll
+    for (int b = 0; b < F::B; b++) F::load(buf[b], pl, rbase + min(j * F::B + b, rows_here - 1), S.nblk, uc);
+  };
+  auto consume = [&](uint32_t p, uint32_t j, const typename F::Raw* buf, const typename F::X& X_) {
     float* rp = red + (size_t)(p * S.T + ks) * S.rows_per_wg + rg * rpg;
-    for (uint32_t i0 = 0; i0 < rpg; i0 += F::B) {
-      typename F::Raw raw[F::B];
 #pragma unroll
-      for (int b = 0; b < F::B; b++) {
-        uint32_t row = row0 + i0 + b;
-        if (i0 + b < rpg && row < S.n_rows) F::load(raw[b], pl, row, S.nblk, uc);
-      }
-#pragma unroll
-      for (int b = 0; b < F::B; b++) {
-        uint32_t row = row0 + i0 + b;
-        if (i0 + b < rpg && row < S.n_rows) {
-          float part = F::dot(raw[b], X_);
-          part = wave_sum(uvalid ? part : 0.0f);
-          if (lane == 0) rp[i0 + b] = part;
-        }
+    for (int b = 0; b < F::B; b++) {
+      const uint32_t rl = j * F::B + b;
+      if (rl < rows_here) {  // clamped duplicate rows are loaded (static load count) but not reduced
+        float part = F::dot(buf[b], X_);
+        part = wave_sum_to_lane63(uvalid ? part : 0.0f);
+        if (lane == 63) rp[rl] = part;
       }
     }
+  };
+
+  typename F::Raw A[F::B], Bq[F::B];
+  LGH_STAMP(0);
+  uint32_t ip = 0, ij = 0;  // (pass, batch) of the next item to issue
+  auto advance = [&]() { if (++ij == nb) { ij = 0; ++ip; } };
+  uint32_t ap = 0, aj = 0, bp = 0, bj = 0;
+  if (has_rows) { issue(0, 0, A); advance(); }
+  typename F::X X_;
+  const float* xcur = S.pass[0].x;
+  float ss = 0.0f;
+  F::load_x(X_, xcur, L.norm_w, ss, nrm, uc);
+  if (nrm && rg == 0) {  // this wave's share of sum(x^2); the epilogue adds the T shares
+    ss = wave_sum_to_lane63(uvalid ? ss : 0.0f);
+    if (lane == 63) ssq[ks] = ss;
   }
+  LGH_STAMP(1);
+  if (!has_rows) return;
+  auto fix_x = [&](uint32_t p) {
+    const float* xp = S.pass[p].x;
+    if (xp != xcur) { xcur = xp; float dummy = 0.0f; F::load_x(X_, xcur, L.norm_w, dummy, false, uc); }
+  };
+  uint32_t remaining = (uint32_t)S.npass * nb;
+  while (remaining > 2) {   // steady state: every issue / consume is unconditional
+    bp = ip; bj = ij; issue(ip, ij, Bq); advance();
+    fix_x(ap);
+    consume(ap, aj, A, X_);
+    ap = ip; aj = ij; issue(ip, ij, A); advance();
+    fix_x(bp);
+    consume(bp, bj, Bq, X_);
+    remaining -= 2;
+  }
+  if (remaining == 2) {
+    bp = ip; bj = ij; issue(ip, ij, Bq);
+    fix_x(ap);
+    consume(ap, aj, A, X_);
+    fix_x(bp);
+    consume(bp, bj, Bq, X_);
+  } else {
+    fix_x(ap);
+    consume(ap, aj, A, X_);
+  }
+  LGH_STAMP(3);
 }
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
 // Per-row epilogue, one thread per row (or per row pair for RoPE)
-__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red) {
+__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
+                                            const float* ssq) {
   const uint32_t t = threadIdx.x;
   const uint32_t rbase = wg * S.rows_per_wg;
+  float inv = 1.0f;
+  if (L.do_norm) {  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
+    float tot = 0.0f;
+    for (uint32_t ks = 0; ks < S.T; ks++) tot += ssq[ks];
+    inv = 1.0f / __builtin_sqrtf(tot / (float)L.k + L.eps);
+  }
   auto rowval = [&](int p, uint32_t rl) {
     float v = 0.0f;
     for (uint32_t ks = 0; ks < S.T; ks++) v += red[(size_t)(p * S.T + ks) * S.rows_per_wg + rl];
-    return v;
+    return v * inv;
   };
   if (S.epi == EPI_ROPE_Q || S.epi == EPI_ROPE_K) {
     uint32_t rl = 2 * t, row = rbase + rl;
@@ -393,25 +491,25 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
 template <uint32_t MASK, int MAXT>
 __global__ void __launch_bounds__(MAXT) mv_kernel(const MvLaunch L) {
   __shared__ float red[kRedFloats];
-  __shared__ float wsum[16];
+  __shared__ float ssq[16];
   int s = 0;
   const uint32_t bid = blockIdx.x;
   if (L.nseg > 1 && bid >= L.seg[1].wg_begin) s = 1;
   if (L.nseg > 2 && bid >= L.seg[2].wg_begin) s = 2;
   const MvSeg& S = L.seg[s];
   const uint32_t wg = bid - S.wg_begin;
-  float inv = 1.0f;
-  if (L.do_norm) inv = block_inv_rms(S.pass[0].x, L.k, L.eps, wsum);
   switch (S.type) {
-    case LGH_TYPE_Q4_K: if constexpr (MASK & M_Q4K) mv_rows<FmtQ4K>(L, S, wg, inv, red); break;
-    case LGH_TYPE_Q5_K: if constexpr (MASK & M_Q5K) mv_rows<FmtQ5K>(L, S, wg, inv, red); break;
-    case LGH_TYPE_Q6_K: if constexpr (MASK & M_Q6K) mv_rows<FmtQ6K>(L, S, wg, inv, red); break;
-    case LGH_TYPE_Q8_0: if constexpr (MASK & M_Q80) mv_rows<FmtQ80>(L, S, wg, inv, red); break;
-    case LGH_TYPE_Q4_0: if constexpr (MASK & M_Q40) mv_rows<FmtQ40>(L, S, wg, inv, red); break;
+    case LGH_TYPE_Q4_K: if constexpr (MASK & M_Q4K) mv_rows<FmtQ4K>(L, S, wg, red, ssq); break;
+    case LGH_TYPE_Q5_K: if constexpr (MASK & M_Q5K) mv_rows<FmtQ5K>(L, S, wg, red, ssq); break;
+    case LGH_TYPE_Q6_K: if constexpr (MASK & M_Q6K) mv_rows<FmtQ6K>(L, S, wg, red, ssq); break;
+    case LGH_TYPE_Q8_0: if constexpr (MASK & M_Q80) mv_rows<FmtQ80>(L, S, wg, red, ssq); break;
+    case LGH_TYPE_Q4_0: if constexpr (MASK & M_Q40) mv_rows<FmtQ40>(L, S, wg, red, ssq); break;
     default: break;
   }
   __syncthreads();
-  mv_epilogue(L, S, wg, red);
+  LGH_STAMP(4);
+  mv_epilogue(L, S, wg, red, ssq);
+  LGH_STAMP(5);
 }
 
 static uint32_t type_mask(int t) {
@@ -422,14 +520,15 @@ static uint32_t type_mask(int t) {
 }
 
 static uint32_t unit_elems(int t) { return t == LGH_TYPE_Q6_K ? 64u : 32u; }
-static uint32_t rows_in_flight(int t) {
-  switch (t) {
-    case LGH_TYPE_Q4_K: return FmtQ4K::B; case LGH_TYPE_Q5_K: return FmtQ5K::B; case LGH_TYPE_Q6_K: return FmtQ6K::B;
-    case LGH_TYPE_Q8_0: return FmtQ80::B; case LGH_TYPE_Q4_0: return FmtQ40::B; default: return 1;
-  }
-}
 
-hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan) {
+// waves a CU holds at this format's register budget (16 at <=128 VGPRs, 12 at <=168, 8 at <=256)
+static uint32_t waves_per_cu(int t) { return t == LGH_TYPE_Q6_K ? 8u : (t == LGH_TYPE_Q5_K ? 12u : 16u); }
+
+// Geometry for one weight shape.  `launch_rows` = output rows of the WHOLE launch (all segments), so the
+// segments of a fused QKV launch share one rows-per-wave figure; npass = passes over those rows.
+// Aim: about one resident wave per hardware slot (256 CUs x waves_per_cu), each with >= 1 row-pass, so
+// small matrices put all their bytes in flight at once and large ones run as a single persistent round.
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows) {
   if (!type_mask(dev_type) || k == 0 || n_rows == 0 || npass < 1 || npass > 4) return hipErrorInvalidValue;
   uint32_t ue = unit_elems(dev_type);
   if (k % ue) return hipErrorInvalidValue;
@@ -438,16 +537,12 @@ hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan*
   const uint32_t maxT = (dev_type == LGH_TYPE_Q5_K || dev_type == LGH_TYPE_Q6_K) ? 8u : 16u;
   if (T > maxT) return hipErrorInvalidValue;  // K beyond every supported model (see launch bounds below)
   uint32_t G = T == 1 ? 4 : (T == 2 ? 2 : 1);
-  uint32_t B = rows_in_flight(dev_type);
-  uint32_t occ = 16 / (T * G);
-  if (occ < 1) occ = 1;
-  if (occ > 4) occ = 4;
-  uint32_t rpg = B;
-  const uint32_t max_wg = kNumCU * occ * 4;
-  while ((n_rows + G * rpg - 1) / (G * rpg) > max_wg && (uint32_t)npass * T * G * (rpg + B) <= (uint32_t)kRedFloats)
-    rpg += B;
-  while ((uint32_t)npass * T * G * rpg > (uint32_t)kRedFloats && rpg > 2) rpg -= 2;
-  if (rpg & 1) rpg += 1;
+  if (launch_rows < n_rows) launch_rows = n_rows;
+  const uint32_t slots = kNumCU * waves_per_cu(dev_type);
+  uint32_t rpg = (uint32_t)(((uint64_t)launch_rows * T + slots - 1) / slots);  // rows per wave
+  if (rpg < 1) rpg = 1;
+  while ((uint32_t)npass * T * G * rpg > (uint32_t)kRedFloats && rpg > 1) rpg--;
+  if ((G * rpg) & 1) rpg += 1;  // RoPE epilogues rotate row pairs (2i, 2i+1) inside one workgroup
   plan->units = units;
   plan->T = T;
   plan->G = G;
@@ -455,6 +550,17 @@ hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan*
   plan->n_wg = (n_rows + plan->rows_per_wg - 1) / plan->rows_per_wg;
   plan->threads = T * G * 64;
   return hipSuccess;
+}
+
+int mv_symbol(const MvLaunch& L) {
+  uint32_t mask = 0;
+  for (int i = 0; i < L.nseg; i++) mask |= type_mask(L.seg[i].type);
+  switch (mask) {
+    case M_Q4K: return LGH_SYM_MV_Q4K; case M_Q80: return LGH_SYM_MV_Q80; case M_Q40: return LGH_SYM_MV_Q40;
+    case M_Q5K: return LGH_SYM_MV_Q5K; case M_Q6K: return LGH_SYM_MV_Q6K;
+    case M_Q4K | M_Q6K: return LGH_SYM_MV_Q4K_Q6K; case M_Q5K | M_Q6K: return LGH_SYM_MV_Q5K_Q6K;
+    default: return LGH_SYM_MV_ALL;
+  }
 }
 
 hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {

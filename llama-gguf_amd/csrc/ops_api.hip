@@ -9,6 +9,12 @@
 
 using namespace lgh;
 
+#ifdef LGH_STAMPS
+namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); }
+#include <algorithm>
+#include <cstdio>
+#endif
+
 namespace {
 
 struct Tmp {  // bare context: stream, device state words, tracked allocations
@@ -173,22 +179,32 @@ int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, 
 }
 
 int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, size_t k, size_t n, int mode, int iters,
-                      double* avg_us) {
+                      int copies, double* avg_us) {
   Tmp t(device);
   if (t.rc) return t.rc;
   if (!avg_us || iters <= 0) return LGH_INVALID_ARGUMENT;
   const uint32_t be = blk_elems((int)type);
   if (!be || k % be) return LGH_SHAPE_MISMATCH;
   const size_t nbytes = n * (k / be) * blk_bytes((int)type);
-  DevWeight W, W2;
+  if (copies < 1) copies = 1;
+  if (copies > 64) copies = 64;
+  // `copies` distinct device copies are cycled so that consecutive launches do not re-read weights that the
+  // 256 MiB Infinity Cache still holds (in the engine a token streams GBs between two uses of a matrix)
+  std::vector<DevWeight> Ws(copies), W2s(copies);
   int rc;
-  if ((rc = upload_matrix(t.c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
-  if (mode == 2 && (rc = upload_matrix(t.c, W2, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w2 ? w2 : w, nbytes))) return rc;
+  for (int i = 0; i < copies; i++) {
+    if ((rc = upload_matrix(t.c, Ws[i], (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
+    if (mode == 2 && (rc = upload_matrix(t.c, W2s[i], (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w2 ? w2 : w, nbytes))) return rc;
+  }
+  int cur = 0;
   std::vector<float> hx(k), hw(k, 1.0f);
   for (size_t i = 0; i < k; i++) hx[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
   float *dx = t.up(hx.data(), k), *dnw = t.up(hw.data(), k), *dout = t.up(nullptr, n);
   if (!dx || !dnw || !dout) return LGH_ALLOCATION_FAILED;
   auto once = [&]() -> int {
+    DevWeight& W = Ws[cur];
+    DevWeight& W2 = W2s[cur];
+    cur = (cur + 1) % copies;
     if (mode == 2) {
       SegSpec sp;
       sp.npass = 2;
@@ -216,6 +232,26 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
   if (rc) return rc;
   if (e != hipSuccess) return LGH_OPERATION_FAILED;
   *avg_us = (double)ms * 1000.0 / iters;
+#ifdef LGH_STAMPS
+  {  // phase profile of the LAST launch: per stamp, min / median / max over workgroups, relative to the first start
+    std::vector<unsigned long long> st(8192 * 8);
+    if (lgh::mv_read_stamps(st.data(), st.size()) == hipSuccess) {
+      MvPlan plan;
+      (void)mv_plan(Ws[0].type, (uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n);
+      size_t nwg = std::min<size_t>(plan.n_wg, 8192);
+      unsigned long long t0 = ~0ull;
+      for (size_t w = 0; w < nwg; w++) t0 = std::min(t0, st[w * 8]);
+      std::fprintf(stderr, "  stamps (us since first workgroup start; %zu workgroups x %u threads, rows/wg %u):\n", nwg, plan.threads, plan.rows_per_wg);
+      const char* names[6] = {"start", "x ready", "first item done", "stream done", "after barrier", "end"};
+      for (int i = 0; i < 6; i++) {
+        std::vector<double> v;
+        for (size_t w = 0; w < nwg; w++) v.push_back((double)(st[w * 8 + i] - t0) / 100.0);
+        std::sort(v.begin(), v.end());
+        std::fprintf(stderr, "    %-16s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[i], v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+      }
+    }
+  }
+#endif
   return LGH_OK;
 }
 

@@ -17,7 +17,8 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip.so")
+# LGH_LIB_VARIANT=stamps selects the diagnostic build (in-kernel phase stamps; tools/microbench.py only)
+LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip%s.so" % ("_" + os.environ["LGH_LIB_VARIANT"] if os.environ.get("LGH_LIB_VARIANT") else ""))
 
 # every symbol include/llama_gguf_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
@@ -31,6 +32,11 @@ ABI_SYMBOLS = (
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
 K_COUNT = 16
+# kernel symbols as rocprofv3 prints them (LGH_SYM_* order)
+SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_kernel<16u, 1024>",
+             "lgh::mv_kernel<2u, 512>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
+             "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
+             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other")
 FLAG_NO_GRAPH = 1
 
 
@@ -60,7 +66,9 @@ class Stats(C.Structure):
     _fields_ = [("weight_bytes", C.c_uint64), ("kv_bytes", C.c_uint64), ("scratch_bytes", C.c_uint64),
                 ("tokens_processed", C.c_uint64), ("graph_nodes", C.c_uint64),
                 ("k_launches", C.c_uint64 * K_COUNT), ("k_time_us", C.c_double * K_COUNT),
-                ("k_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64)]
+                ("k_alg_bytes", C.c_uint64 * K_COUNT),
+                ("sym_launches", C.c_uint64 * K_COUNT), ("sym_time_us", C.c_double * K_COUNT),
+                ("sym_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64)]
 
 
 _lib = None
@@ -97,7 +105,7 @@ def load_library() -> C.CDLL:
         "lgh_op_silu_mul": (C.c_int, [C.c_int, vp, vp, vp, sz]),
         "lgh_op_norm_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
-        "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+        "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -235,6 +243,9 @@ class HipGpuInference:
         out["kernels"] = {K_NAMES[i]: {"launches": s.k_launches[i], "time_us": s.k_time_us[i],
                                        "alg_bytes": s.k_alg_bytes[i]}
                           for i in range(len(K_NAMES)) if s.k_launches[i]}
+        out["symbols"] = {SYM_NAMES[i]: {"launches": s.sym_launches[i], "time_us": s.sym_time_us[i],
+                                         "alg_bytes": s.sym_alg_bytes[i]}
+                          for i in range(len(SYM_NAMES)) if s.sym_launches[i]}
         return out
 
     def close(self) -> None:
@@ -346,10 +357,10 @@ def op_silu_mul(gate, up, device: int = 0) -> np.ndarray:
 
 
 def bench_vec_mat(ggml_type: int, w: np.ndarray, k: int, n: int, mode: int = 0, iters: int = 50,
-                  w2: Optional[np.ndarray] = None, device: int = 0) -> float:
+                  w2: Optional[np.ndarray] = None, copies: int = 1, device: int = 0) -> float:
     """Mean device time (µs) of one fused mat-vec launch (hipEvents on the launch stream)."""
     w = np.ascontiguousarray(w)
     us = C.c_double()
     _chk(load_library().lgh_bench_vec_mat(device, ggml_type, w.ctypes.data, w2.ctypes.data if w2 is not None else None,
-                                          k, n, mode, iters, C.byref(us)), "bench_vec_mat")
+                                          k, n, mode, iters, copies, C.byref(us)), "bench_vec_mat")
     return us.value
