@@ -41,12 +41,15 @@ __host__ __device__ inline uint32_t blk_bytes(int t) {
   }
 }
 
+constexpr int kDevQ4K_T16 = 1012;  // device-only type tag: Q4_K in the 16-row tile layout of matvec_mfma.hip
+
 // ---------------------------------------------------------------------------------------------
 // Device weight layouts (what lgh_upload_tensor leaves in HBM).  Byte counts equal the GGUF payload;
 // formats whose blocks are not 16-byte multiples are split into per-matrix planes so that every
 // lane load is an aligned 16-byte (or 8-byte) access.
 //
-//   Q4_K  native 144-B blocks {d,dmin,scales[12],qs[128]}                       plane0
+//   Q4_K  16-row x 256-element tiles of 2304 B for the int8-MFMA kernel (matvec_mfma.hip)   plane0
+//         (native 144-B blocks only when k is not a multiple of 256 — never for GGUF K-quants)
 //   Q5_K  native 176-B blocks {d,dmin,scales[12],qh[32],qs[128]}                plane0
 //   Q6_K  plane0 ql[128]/blk, plane1 qh[64]/blk, plane2 scales[16]/blk, plane3 d(f16)/blk
 //   Q8_0  plane0 qs[32]/blk,  plane1 d(f16)/blk
@@ -123,6 +126,7 @@ struct MvLaunch {
   const float* norm_w;
   const int* pos;            // device: current position (RoPE / cache epilogues)
   const float* rope_cs;      // [max_seq][head_dim/2][2] cos,sin
+  uint32_t red_floats;       // LDS floats for per-row partial sums (max over segments)
   MvSeg seg[3];
 };
 
@@ -130,13 +134,19 @@ struct MvLaunch {
 // host-side launchers (defined in the .hip files)
 // ---------------------------------------------------------------------------------------------
 struct MvPlan {               // geometry chosen by the host for one weight shape
-  uint32_t units, T, G, rows_per_wg, n_wg, threads;
+  uint32_t units, T, G, rows_per_wg, n_wg, threads, red_floats;
 };
 
 // matvec
-hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows,
+                   uint32_t wave_cap);
+uint32_t mv_wave_cap(int dev_type);  // waves of the one workgroup per CU for this format (0 = not a fused format)
 hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
-int mv_symbol(const MvLaunch& L);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
+int mv_symbol(const MvLaunch& L);
+// int8-MFMA path (matvec_mfma.hip): Q4_K in the tile16 layout
+hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
+hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
+hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
 hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
                              float eps, const float* resid, hipStream_t st);
 

@@ -43,8 +43,17 @@ __device__ __forceinline__ float fma4(uint32_t v, const float* x, float acc) {
 // Makes `v` opaque to the optimizer at this point (no instruction is emitted).  Used after nibble masks so
 // that `(m >> 8) & 0xFF` stays a single v_cvt_f32_ubyte1 instead of being re-folded into v_bfe_u32 + cvt.
 __device__ __forceinline__ uint32_t opaque(uint32_t v) {
-  asm("" : "+v"(v));
+  asm volatile("" : "+v"(v));
   return v;
+}
+
+// the 4 bytes of `v` dotted with x[0..3], as a fresh chain (first term is a plain multiply)
+__device__ __forceinline__ float fma4z(uint32_t v, const float* x) {
+  float acc = ub0(v) * x[0];
+  acc = __builtin_fmaf(ub1(v), x[1], acc);
+  acc = __builtin_fmaf(ub2(v), x[2], acc);
+  acc = __builtin_fmaf(ub3(v), x[3], acc);
+  return acc;
 }
 
 // full-wave (64 lanes) sum; every lane gets the result; fixed order -> deterministic

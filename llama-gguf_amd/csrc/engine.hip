@@ -16,6 +16,7 @@
 //   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -74,7 +75,7 @@ LayoutInfo layout_for(int src_type) {
 }
 
 bool fused_type(int t) {
-  return t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
+  return t == kDevQ4K_T16 || t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
 }
 
 // Upload one matrix (or expert `slot` of a stack, or the whole stack when slot < 0) given in native
@@ -84,11 +85,16 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
   const uint32_t sbe = blk_elems(src_type), sbb = blk_bytes(src_type);
   if (!sbe) return fail(c, LGH_UNSUPPORTED_DTYPE, "unsupported ggml type " + std::to_string(src_type));
   if (k % sbe) return fail(c, LGH_SHAPE_MISMATCH, "in_features not a multiple of the block size");
-  const LayoutInfo li = layout_for(src_type);
+  LayoutInfo li = layout_for(src_type);
   const uint64_t per_expert_src = (uint64_t)n * (k / sbe) * sbb;
   const uint32_t n_in_payload = slot < 0 ? n_stack : 1;
   if (nbytes != per_expert_src * n_in_payload) return fail(c, LGH_SHAPE_MISMATCH, "tensor byte size does not match its shape");
-  const uint64_t blocks_per_expert = (uint64_t)n * (k / li.belems);
+  uint64_t blocks_per_expert = (uint64_t)n * (k / li.belems);
+  const bool t16 = src_type == LGH_TYPE_Q4_K;   // int8-MFMA tile layout: rows padded to 16
+  if (t16) {
+    li.dev_type = kDevQ4K_T16;
+    blocks_per_expert = (uint64_t)((n + 15) / 16) * 16 * (k / 256);
+  }
   if (!W.present()) {
     uint64_t off = 0;
     uint64_t plane_off[4] = {0, 0, 0, 0};
@@ -107,12 +113,13 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
     W.k = k; W.n = n; W.n_stack = n_stack;
     W.bytes = 0;
     for (int p = 0; p < li.nplanes; p++) W.bytes += W.stack_stride[p];  // per expert
+    if (t16) W.bytes = per_expert_src;                                  // algorithmic bytes exclude the row padding
     c->stats.weight_bytes += (li.dev_type == LGH_TYPE_F32 ? (uint64_t)n * k * 4 : per_expert_src) * n_stack;
   } else if (W.src_type != src_type || W.k != k || W.n != n || W.n_stack != n_stack) {
     return fail(c, LGH_SHAPE_MISMATCH, "expert tensors of one stack differ in type or shape");
   }
   const uint32_t e0 = slot < 0 ? 0 : (uint32_t)slot;
-  if (li.dev_type == src_type && li.nplanes == 1) {  // native layout: straight copy
+  if (li.dev_type == src_type && li.nplanes == 1 && !t16) {  // native layout: straight copy
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy((void*)(W.plane[0] + (uint64_t)e0 * W.stack_stride[0]), host, nbytes, hipMemcpyHostToDevice));
     return LGH_OK;
   }
@@ -123,6 +130,8 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
     const uint8_t* src = (const uint8_t*)raw + (uint64_t)i * per_expert_src;
     if (li.dev_type == LGH_TYPE_F32) {
       e = dequant_launch(src_type, src, (float*)(W.plane[0] + (uint64_t)(e0 + i) * W.stack_stride[0]), (uint64_t)n * k, c->stream);
+    } else if (t16) {
+      e = repack_q4k_t16_launch(src, W.base + (uint64_t)(e0 + i) * W.stack_stride[0], n, k / 256, c->stream);
     } else {
       uint64_t po[4];
       for (int p = 0; p < 4; p++) po[p] = (uint64_t)(W.plane[p] - W.base) + (uint64_t)(e0 + i) * W.stack_stride[p];
@@ -181,7 +190,7 @@ int drain_prof(lgh_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // fused mat-vec launch assembly
 // ------------------------------------------------------------------------------------------------
-int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k) {
+static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma) {
   MvLaunch L;
   std::memset(&L, 0, sizeof(L));
   L.nseg = nseg;
@@ -193,18 +202,28 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
   L.rope_cs = c->rope_cs;
   uint32_t wg = 0, threads = 0, launch_rows = 0;
   uint64_t alg = 0;
-  for (int s = 0; s < nseg; s++) launch_rows += specs[s].W[0]->n;
+  uint32_t wave_cap = 16;
+  for (int s = 0; s < nseg; s++) {
+    launch_rows += specs[s].W[0]->n;
+    if (!mfma) wave_cap = std::min(wave_cap, mv_wave_cap(specs[s].W[0]->type));
+  }
+  if (!mfma && nseg > 1) {  // mixed-type launches run in the 512-thread instantiations
+    for (int s = 1; s < nseg; s++)
+      if (specs[s].W[0]->type != specs[0].W[0]->type) wave_cap = std::min(wave_cap, 8u);
+  }
   for (int s = 0; s < nseg; s++) {
     const SegSpec& sp = specs[s];
     const DevWeight& W0 = *sp.W[0];
     MvPlan plan;
-    if (mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan, launch_rows) != hipSuccess)
+    hipError_t pe = mfma ? mvq_plan(W0.k, W0.n, sp.npass, &plan, launch_rows)
+                         : mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan, launch_rows, wave_cap);
+    if (pe != hipSuccess)
       return fail(c, LGH_UNSUPPORTED, "no fused mat-vec plan for type " + std::to_string(W0.type) + " k=" + std::to_string(W0.k));
     MvSeg& S = L.seg[s];
     S.type = W0.type;
     S.epi = sp.epi;
     S.n_rows = W0.n;
-    S.nblk = W0.k / layout_for(W0.src_type).belems;
+    S.nblk = mfma ? W0.k / 256 : W0.k / layout_for(W0.src_type).belems;
     S.units = plan.units; S.T = plan.T; S.G = plan.G;
     S.rows_per_wg = plan.rows_per_wg;
     S.wg_begin = wg;
@@ -222,9 +241,26 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
     S.max_seq = c->d.max_seq_len;
     wg += plan.n_wg;
     if (plan.threads > threads) threads = plan.threads;
+    if (plan.red_floats > L.red_floats) L.red_floats = plan.red_floats;
   }
   alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
+  if (mfma) return run_k(c, cls, LGH_SYM_MVQ_Q4K, alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
+}
+
+// Segments are independent (disjoint outputs), so a launch whose matrices live in different kernel families
+// (Q4_K on the matrix cores, the rest on the VALU kernel) is issued as one launch per family.
+int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k) {
+  SegSpec a[3], b[3];
+  int na = 0, nb = 0;
+  for (int s = 0; s < nseg; s++) {
+    if (specs[s].W[0]->type == kDevQ4K_T16) a[na++] = specs[s];
+    else b[nb++] = specs[s];
+  }
+  int rc = LGH_OK;
+  if (na && (rc = launch_mv_group(c, cls, a, na, norm_w, k, true))) return rc;
+  if (nb && (rc = launch_mv_group(c, cls, b, nb, norm_w, k, false))) return rc;
+  return rc;
 }
 
 // one Linear with optional norm prologue / residual epilogue, any device type

@@ -18,6 +18,7 @@
 //     residual add / SwiGLU / RoPE + KV-cache write / MoE expert mixing are epilogues, so a dense
 //     layer is 5 launches instead of the reference's ~20.
 #include "device_utils.h"
+#include "mv_epilogue.h"
 
 namespace lgh {
 
@@ -123,13 +124,20 @@ struct FmtQ4K {
     m_lo = ub0(m2); m_hi = ub1(m2);
   }
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
-    float alo = 0.0f, ahi = 0.0f;
+    // one short FMA chain per dword (8 independent chains): a dependent v_fmac issues only every ~8 cycles
+    float pl[2], ph[2];  // two chains per nibble half: enough ILP to cover the dependent-FMA latency, few registers
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t v = r.qs[w];
-      alo = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, alo);
-      ahi = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ahi);
+      if (w < 2) {
+        pl[w] = fma4z(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w);
+        ph[w] = fma4z(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w);
+      } else {
+        pl[w - 2] = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, pl[w - 2]);
+        ph[w - 2] = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ph[w - 2]);
+      }
     }
+    const float alo = pl[0] + pl[1], ahi = ph[0] + ph[1];
     float sc_lo, sc_hi, m_lo, m_hi;
     scales(r.hd, X_, sc_lo, sc_hi, m_lo, m_hi);
     float d = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
@@ -165,15 +173,21 @@ struct FmtQ5K {
     r.qs = ldg_nt128(b + 48 + (u & 7) * 16);
   }
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
-    float alo = 0.0f, ahi = 0.0f;
+    float pl[2], ph[2];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t v = r.qs[w], t = r.qh[w] >> X_.qsh;
       uint32_t qlo = (v & 0x0F0F0F0Fu) | ((t << 4) & 0x10101010u);
       uint32_t qhi = ((v >> 4) & 0x0F0F0F0Fu) | ((t << 3) & 0x10101010u);
-      alo = fma4(opaque(qlo), X_.v[0] + 4 * w, alo);
-      ahi = fma4(opaque(qhi), X_.v[1] + 4 * w, ahi);
+      if (w < 2) {
+        pl[w] = fma4z(opaque(qlo), X_.v[0] + 4 * w);
+        ph[w] = fma4z(opaque(qhi), X_.v[1] + 4 * w);
+      } else {
+        pl[w - 2] = fma4(opaque(qlo), X_.v[0] + 4 * w, pl[w - 2]);
+        ph[w - 2] = fma4(opaque(qhi), X_.v[1] + 4 * w, ph[w - 2]);
+      }
     }
+    const float alo = pl[0] + pl[1], ahi = ph[0] + ph[1];
     float sc_lo, sc_hi, m_lo, m_hi;
     FmtQ4K::X sx;  // reuse the Q4_K scale unpack (same 12-byte packing)
     sx.sh = X_.sh; sx.upper = X_.upper;
@@ -214,7 +228,7 @@ struct FmtQ6K {
     r.d = ldg_nt16(pl[3] + blk * 2);
   }
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;  // four independent chains (one per quarter)
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t a = r.qa[w], b = r.qb[w], h = r.qh[w];
@@ -260,11 +274,18 @@ struct FmtQ80 {
     r.d = ldg_nt16(pl[1] + blk * 2);
   }
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
-    float a = 0.0f;
+    float pa[2], pb[2];
 #pragma unroll
-    for (int w = 0; w < 4; w++) a = fma4(opaque(r.q0[w] ^ 0x80808080u), X_.v[0] + 4 * w, a);
+    for (int w = 0; w < 2; w++) {
+      pa[w] = fma4z(opaque(r.q0[w] ^ 0x80808080u), X_.v[0] + 4 * w);
+      pb[w] = fma4z(opaque(r.q1[w] ^ 0x80808080u), X_.v[1] + 4 * w);
+    }
 #pragma unroll
-    for (int w = 0; w < 4; w++) a = fma4(opaque(r.q1[w] ^ 0x80808080u), X_.v[1] + 4 * w, a);
+    for (int w = 2; w < 4; w++) {
+      pa[w - 2] = fma4(opaque(r.q0[w] ^ 0x80808080u), X_.v[0] + 4 * w, pa[w - 2]);
+      pb[w - 2] = fma4(opaque(r.q1[w] ^ 0x80808080u), X_.v[1] + 4 * w, pb[w - 2]);
+    }
+    const float a = (pa[0] + pa[1]) + (pb[0] + pb[1]);
     return h2f(r.d) * __builtin_fmaf(-128.0f, X_.s, a);
   }
 };
@@ -273,7 +294,7 @@ struct FmtQ80 {
 // planes: qs[16], d per block; unit = one block: low nibble j -> element j, high nibble -> 16+j
 // (dequant.rs:16-30);  (q-8) folded in as sum(q*x) - 8*sum(x).
 struct FmtQ40 {
-  static constexpr int B = 3;
+  static constexpr int B = 2;
   static constexpr uint32_t UNIT = 32;
   struct X { float v[2][16]; float s; };
   struct Raw { u32x4 qs; uint32_t d; };
@@ -290,19 +311,24 @@ struct FmtQ40 {
     r.d = ldg_nt16(pl[1] + blk * 2);
   }
   static __device__ __forceinline__ float dot(const Raw& r, const X& X_) {
-    float alo = 0.0f, ahi = 0.0f;
+    float pl[2], ph[2];  // two chains per nibble half: enough ILP to cover the dependent-FMA latency, few registers
 #pragma unroll
     for (int w = 0; w < 4; w++) {
       uint32_t v = r.qs[w];
-      alo = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, alo);
-      ahi = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ahi);
+      if (w < 2) {
+        pl[w] = fma4z(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w);
+        ph[w] = fma4z(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w);
+      } else {
+        pl[w - 2] = fma4(opaque(v & 0x0F0F0F0Fu), X_.v[0] + 4 * w, pl[w - 2]);
+        ph[w - 2] = fma4(opaque((v >> 4) & 0x0F0F0F0Fu), X_.v[1] + 4 * w, ph[w - 2]);
+      }
     }
+    const float alo = pl[0] + pl[1], ahi = ph[0] + ph[1];
     return h2f(r.d) * __builtin_fmaf(-8.0f, X_.s, alo + ahi);
   }
 };
 
 // ------------------------------------------------------------------------------------------ body
-constexpr int kRedFloats = 4096;
 
 // block-wide variant for the f32 kernel
 __device__ __forceinline__ float block_inv_rms(const float* x, uint32_t k, float eps, float* wsum) {
@@ -325,25 +351,35 @@ __device__ __forceinline__ float block_inv_rms(const float* x, uint32_t k, float
   return 1.0f / rms;
 }
 
-// The streaming loop of one wave.  Work items = (pass, batch of F::B rows), flattened so the pipeline runs
-// across passes (gate -> up).  Two register buffers alternate: the loads of item i+1 are in flight while
-// item i is being reduced, and the very first loads are issued before x is even read.  Every load of an item
-// is unconditional (out-of-range rows are clamped onto the last valid one) so that hipcc can count the
-// outstanding loads statically and emit partial `s_waitcnt vmcnt(N)` instead of draining the next batch.
+constexpr int kXPT = 8;  // float4 x-loads a thread keeps in flight while staging x into LDS
+
+// Workgroup prologue + the streaming loop of one wave.
+//
+// Prologue (whole workgroup, ONE workgroup per CU): x is read from L2 exactly once per workgroup — each thread
+// fetches a few float4s, applies the norm weight, accumulates its share of sum(x^2) and parks the values in LDS,
+// from where every wave then pulls the K-slice its lanes own into registers.  (Letting each wave fetch its own
+// slice from L2 cost as many bytes as the weights themselves: 4096 waves x 16 KB on the gate/up launch.)
+// The first weight loads are issued BEFORE x is waited for, and the barrier that publishes x in LDS does not
+// drain them (explicit lgkmcnt-only wait + s_barrier).
+//
+// Stream: work items = (pass, batch of F::B rows), flattened so the pipeline runs across passes (gate -> up).
+// Two register buffers alternate: the loads of item i+1 are in flight while item i is being reduced.  Every
+// load of an item is unconditional (out-of-range rows are clamped onto the last valid one) so that hipcc counts
+// the outstanding loads statically and emits partial `s_waitcnt vmcnt(N)` instead of draining the next batch.
 template <class F>
-__device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint32_t wg, float* red, float* ssq) {
-  const uint32_t lane = threadIdx.x & 63;
+__device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint32_t wg, float* xs, float* red, float* ssq) {
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
   // wave-uniform bookkeeping lives in SGPRs (readfirstlane): no vector divides, no exec-masked branches
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (wave >= S.T * S.G) return;
-  const uint32_t ks = wave % S.T, rg = wave / S.T;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool active = wave < S.T * S.G;
+  const uint32_t ks = active ? wave % S.T : 0, rg = active ? wave / S.T : 0;
   const uint32_t u = ks * 64 + lane;
   const bool uvalid = u < S.units;
   const uint32_t uc = uvalid ? u : S.units - 1;
   const uint32_t rpg = S.rows_per_wg / S.G;
   const uint32_t row0 = wg * S.rows_per_wg + rg * rpg;
   const bool nrm = L.do_norm != 0;
-  const bool has_rows = row0 < S.n_rows;
+  const bool has_rows = active && row0 < S.n_rows;
   const uint32_t rows_here = has_rows ? min(rpg, S.n_rows - row0) : 0;
   const uint32_t nb = (rows_here + F::B - 1) / F::B;
   const uint32_t rbase = has_rows ? row0 : 0;
@@ -367,28 +403,72 @@ __device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint3
         part = wave_sum_to_lane63(uvalid ? part : 0.0f);
         if (lane == 63) rp[rl] = part;
       }
+      __builtin_amdgcn_sched_barrier(0);  // keep each row's work together: hoisting all converts up front spills
     }
   };
 
   typename F::Raw A[F::B], Bq[F::B];
   LGH_STAMP(0);
+#ifdef LGH_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime();
+#endif
   uint32_t ip = 0, ij = 0;  // (pass, batch) of the next item to issue
   auto advance = [&]() { if (++ij == nb) { ij = 0; ++ip; } };
   uint32_t ap = 0, aj = 0, bp = 0, bj = 0;
-  if (has_rows) { issue(0, 0, A); advance(); }
-  typename F::X X_;
-  const float* xcur = S.pass[0].x;
+
+  // ---- prologue: x -> (x*w, sum x^2) -> LDS, with the first weight batch already in flight
+  const float* xg = S.pass[0].x;
+  const uint32_t k4 = L.k >> 2;
   float ss = 0.0f;
-  F::load_x(X_, xcur, L.norm_w, ss, nrm, uc);
-  if (nrm && rg == 0) {  // this wave's share of sum(x^2); the epilogue adds the T shares
-    ss = wave_sum_to_lane63(uvalid ? ss : 0.0f);
-    if (lane == 63) ssq[ks] = ss;
+  for (uint32_t base = 0; base < k4; base += kXPT * nthr) {
+    f32x4 xv[kXPT], wv[kXPT];
+#pragma unroll
+    for (int j = 0; j < kXPT; j++) {
+      const uint32_t i = base + tid + j * nthr;
+      if (i < k4) xv[j] = reinterpret_cast<const f32x4*>(xg)[i];
+    }
+    if (nrm) {
+#pragma unroll
+      for (int j = 0; j < kXPT; j++) {
+        const uint32_t i = base + tid + j * nthr;
+        if (i < k4) wv[j] = reinterpret_cast<const f32x4*>(L.norm_w)[i];
+      }
+    }
+    if (base == 0 && has_rows) { issue(0, 0, A); advance(); }
+#pragma unroll
+    for (int j = 0; j < kXPT; j++) {
+      const uint32_t i = base + tid + j * nthr;
+      if (i < k4) {
+        f32x4 v = xv[j];
+        if (nrm) {
+          ss = __builtin_fmaf(v.x, v.x, ss);
+          ss = __builtin_fmaf(v.y, v.y, ss);
+          ss = __builtin_fmaf(v.z, v.z, ss);
+          ss = __builtin_fmaf(v.w, v.w, ss);
+          v = v * wv[j];
+        }
+        reinterpret_cast<f32x4*>(xs)[i] = v;
+      }
+    }
   }
+  if (nrm) {  // this wave's share of sum(x^2); the epilogue adds the shares of all waves
+    ss = wave_sum_to_lane63(ss);
+    if (lane == 63) ssq[wave] = ss;
+  }
+  // publish x: wait for the LDS writes only — the weight loads stay in flight across the barrier
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   LGH_STAMP(1);
   if (!has_rows) return;
-  auto fix_x = [&](uint32_t p) {
+
+  typename F::X X_;
+  const float* xcur = xg;
+  {
+    float dummy = 0.0f;
+    F::load_x(X_, xs, nullptr, dummy, false, uc);
+  }
+  auto fix_x = [&](uint32_t p) {  // a later pass with a different input vector (MoE down): straight from L2
     const float* xp = S.pass[p].x;
-    if (xp != xcur) { xcur = xp; float dummy = 0.0f; F::load_x(X_, xcur, L.norm_w, dummy, false, uc); }
+    if (xp != xcur) { xcur = xp; float dummy = 0.0f; F::load_x(X_, xcur, nullptr, dummy, false, uc); }
   };
   uint32_t remaining = (uint32_t)S.npass * nb;
   while (remaining > 2) {   // steady state: every issue / consume is unconditional
@@ -413,85 +493,15 @@ __device__ __forceinline__ void mv_rows(const MvLaunch& L, const MvSeg& S, uint3
   LGH_STAMP(3);
 }
 
-__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
-
-// Per-row epilogue, one thread per row (or per row pair for RoPE)
-__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
-                                            const float* ssq) {
-  const uint32_t t = threadIdx.x;
-  const uint32_t rbase = wg * S.rows_per_wg;
-  float inv = 1.0f;
-  if (L.do_norm) {  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
-    float tot = 0.0f;
-    for (uint32_t ks = 0; ks < S.T; ks++) tot += ssq[ks];
-    inv = 1.0f / __builtin_sqrtf(tot / (float)L.k + L.eps);
-  }
-  auto rowval = [&](int p, uint32_t rl) {
-    float v = 0.0f;
-    for (uint32_t ks = 0; ks < S.T; ks++) v += red[(size_t)(p * S.T + ks) * S.rows_per_wg + rl];
-    return v * inv;
-  };
-  if (S.epi == EPI_ROPE_Q || S.epi == EPI_ROPE_K) {
-    uint32_t rl = 2 * t, row = rbase + rl;
-    if (rl >= S.rows_per_wg || row >= S.n_rows) return;
-    float x0 = rowval(0, rl), x1 = rowval(0, rl + 1);
-    if (S.bias) { x0 += S.bias[row]; x1 += S.bias[row + 1]; }
-    const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim, half = d / 2;
-    const uint32_t head = row / d, i = (row % d) / 2;
-    const float c = L.rope_cs[((size_t)pos * half + i) * 2], s = L.rope_cs[((size_t)pos * half + i) * 2 + 1];
-    float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
-    if (S.epi == EPI_ROPE_Q) {
-      S.out[row] = y0;
-      S.out[row + 1] = y1;
-    } else {
-      float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
-      dst[0] = y0;
-      dst[1] = y1;
-    }
-    return;
-  }
-  if (t >= S.rows_per_wg) return;
-  const uint32_t row = rbase + t;
-  if (row >= S.n_rows) return;
-  float v0 = rowval(0, t);
-  if (S.bias) v0 += S.bias[row];
-  switch (S.epi) {
-    case EPI_STORE: S.out[row] = v0; break;
-    case EPI_RESID: S.out[row] = v0 + S.resid[row]; break;
-    case EPI_SWIGLU: {
-      float up = rowval(1, t);
-      S.out[row] = silu_f(v0) * up;
-      break;
-    }
-    case EPI_V_CACHE: {
-      const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
-      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
-      break;
-    }
-    case EPI_MOE_SWIGLU: {
-      for (int e = 0; 2 * e + 1 < S.npass; e++) {
-        float g = rowval(2 * e, t), up = rowval(2 * e + 1, t);
-        float* o = e == 0 ? S.out : S.out2;
-        o[row] = silu_f(g) * up;
-      }
-      break;
-    }
-    case EPI_MOE_DOWN: {
-      float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
-      for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
-      S.out[row] = acc + S.resid[row];
-      break;
-    }
-    default: break;
-  }
-}
-
-// MAXT: launch bound.  Q4_K / Q8_0 / Q4_0 fit 128 VGPRs (16 waves per CU, up to 1024-thread workgroups
-// for K = 28672); the formats with more planes per unit get 512-thread bounds and more registers.
+// MAXT: launch bound = the widest workgroup of the instantiation (one workgroup per CU): 16 waves at <=128
+// VGPRs for Q4_K / Q8_0 / Q4_0, 12 waves at <=168 for Q5_K, 8 waves at <=256 for Q6_K and mixed-type launches.
+// Dynamic LDS: x[K] | red[npass*T*rows_per_wg] | ssq[16].
 template <uint32_t MASK, int MAXT>
 __global__ void __launch_bounds__(MAXT) mv_kernel(const MvLaunch L) {
-  __shared__ float red[kRedFloats];
-  __shared__ float ssq[16];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  float* red = smem + L.k;
+  float* ssq = red + L.red_floats;
   int s = 0;
   const uint32_t bid = blockIdx.x;
   if (L.nseg > 1 && bid >= L.seg[1].wg_begin) s = 1;
@@ -499,17 +509,20 @@ __global__ void __launch_bounds__(MAXT) mv_kernel(const MvLaunch L) {
   const MvSeg& S = L.seg[s];
   const uint32_t wg = bid - S.wg_begin;
   switch (S.type) {
-    case LGH_TYPE_Q4_K: if constexpr (MASK & M_Q4K) mv_rows<FmtQ4K>(L, S, wg, red, ssq); break;
-    case LGH_TYPE_Q5_K: if constexpr (MASK & M_Q5K) mv_rows<FmtQ5K>(L, S, wg, red, ssq); break;
-    case LGH_TYPE_Q6_K: if constexpr (MASK & M_Q6K) mv_rows<FmtQ6K>(L, S, wg, red, ssq); break;
-    case LGH_TYPE_Q8_0: if constexpr (MASK & M_Q80) mv_rows<FmtQ80>(L, S, wg, red, ssq); break;
-    case LGH_TYPE_Q4_0: if constexpr (MASK & M_Q40) mv_rows<FmtQ40>(L, S, wg, red, ssq); break;
+    case LGH_TYPE_Q4_K: if constexpr (MASK & M_Q4K) mv_rows<FmtQ4K>(L, S, wg, xs, red, ssq); break;
+    case LGH_TYPE_Q5_K: if constexpr (MASK & M_Q5K) mv_rows<FmtQ5K>(L, S, wg, xs, red, ssq); break;
+    case LGH_TYPE_Q6_K: if constexpr (MASK & M_Q6K) mv_rows<FmtQ6K>(L, S, wg, xs, red, ssq); break;
+    case LGH_TYPE_Q8_0: if constexpr (MASK & M_Q80) mv_rows<FmtQ80>(L, S, wg, xs, red, ssq); break;
+    case LGH_TYPE_Q4_0: if constexpr (MASK & M_Q40) mv_rows<FmtQ40>(L, S, wg, xs, red, ssq); break;
     default: break;
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue(L, S, wg, red, ssq);
+  mv_epilogue(L, S, wg, red, ssq, S.T);
   LGH_STAMP(5);
+#ifdef LGH_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 static uint32_t type_mask(int t) {
@@ -521,27 +534,25 @@ static uint32_t type_mask(int t) {
 
 static uint32_t unit_elems(int t) { return t == LGH_TYPE_Q6_K ? 64u : 32u; }
 
-// waves a CU holds at this format's register budget (16 at <=128 VGPRs, 12 at <=168, 8 at <=256)
-static uint32_t waves_per_cu(int t) { return t == LGH_TYPE_Q6_K ? 8u : (t == LGH_TYPE_Q5_K ? 12u : 16u); }
+// waves of the single workgroup a CU runs, by register budget (16 at <=128 VGPRs, 12 at <=168, 8 at <=256)
+uint32_t mv_wave_cap(int t) { return t == LGH_TYPE_Q6_K ? 8u : (t == LGH_TYPE_Q5_K ? 12u : (type_mask(t) ? 16u : 0u)); }
 
-// Geometry for one weight shape.  `launch_rows` = output rows of the WHOLE launch (all segments), so the
-// segments of a fused QKV launch share one rows-per-wave figure; npass = passes over those rows.
-// Aim: about one resident wave per hardware slot (256 CUs x waves_per_cu), each with >= 1 row-pass, so
-// small matrices put all their bytes in flight at once and large ones run as a single persistent round.
-hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows) {
+// Geometry for one weight shape: ONE workgroup per CU (256 of them), T k-slices x G row-groups = wave_cap
+// waves, each workgroup owning a contiguous chunk of launch_rows/256 output rows.  `launch_rows` = output
+// rows of the WHOLE launch (all segments); `wave_cap` = the launch's wave budget (min over its segments).
+hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows,
+                   uint32_t wave_cap) {
   if (!type_mask(dev_type) || k == 0 || n_rows == 0 || npass < 1 || npass > 4) return hipErrorInvalidValue;
   uint32_t ue = unit_elems(dev_type);
   if (k % ue) return hipErrorInvalidValue;
+  if (wave_cap == 0 || wave_cap > mv_wave_cap(dev_type)) wave_cap = mv_wave_cap(dev_type);
   uint32_t units = k / ue;
   uint32_t T = (units + 63) / 64;
-  const uint32_t maxT = (dev_type == LGH_TYPE_Q5_K || dev_type == LGH_TYPE_Q6_K) ? 8u : 16u;
-  if (T > maxT) return hipErrorInvalidValue;  // K beyond every supported model (see launch bounds below)
-  uint32_t G = T == 1 ? 4 : (T == 2 ? 2 : 1);
+  if (T > wave_cap) return hipErrorInvalidValue;  // K beyond every supported model
+  uint32_t G = wave_cap / T;
   if (launch_rows < n_rows) launch_rows = n_rows;
-  const uint32_t slots = kNumCU * waves_per_cu(dev_type);
-  uint32_t rpg = (uint32_t)(((uint64_t)launch_rows * T + slots - 1) / slots);  // rows per wave
+  uint32_t rpg = (launch_rows + kNumCU * G - 1) / (kNumCU * G);  // rows per wave
   if (rpg < 1) rpg = 1;
-  while ((uint32_t)npass * T * G * rpg > (uint32_t)kRedFloats && rpg > 1) rpg--;
   if ((G * rpg) & 1) rpg += 1;  // RoPE epilogues rotate row pairs (2i, 2i+1) inside one workgroup
   plan->units = units;
   plan->T = T;
@@ -549,6 +560,7 @@ hipError_t mv_plan(int dev_type, uint32_t k, uint32_t n_rows, int npass, MvPlan*
   plan->rows_per_wg = G * rpg;
   plan->n_wg = (n_rows + plan->rows_per_wg - 1) / plan->rows_per_wg;
   plan->threads = T * G * 64;
+  plan->red_floats = (uint32_t)npass * T * plan->rows_per_wg;
   return hipSuccess;
 }
 
@@ -563,22 +575,34 @@ int mv_symbol(const MvLaunch& L) {
   }
 }
 
+template <uint32_t MASK, int MAXT>
+static hipError_t mv_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st) {
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_kernel<MASK, MAXT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  if (threads > (uint32_t)MAXT) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((mv_kernel<MASK, MAXT>), dim3(n_wg), dim3(threads), lds, st, L);
+  return hipGetLastError();
+}
+
 hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
   uint32_t mask = 0;
   for (int i = 0; i < L.nseg; i++) mask |= type_mask(L.seg[i].type);
   if (!mask || n_wg == 0 || threads == 0) return hipErrorInvalidValue;
-  const bool wide = (mask & ~(M_Q4K | M_Q80 | M_Q40)) == 0;  // 1024-thread-capable instantiations
-  if (threads > (wide ? 1024u : 512u)) return hipErrorInvalidValue;
-  dim3 grid(n_wg), block(threads);
-  if (mask == M_Q4K) hipLaunchKernelGGL((mv_kernel<M_Q4K, 1024>), grid, block, 0, st, L);
-  else if (mask == M_Q80) hipLaunchKernelGGL((mv_kernel<M_Q80, 1024>), grid, block, 0, st, L);
-  else if (mask == M_Q40) hipLaunchKernelGGL((mv_kernel<M_Q40, 1024>), grid, block, 0, st, L);
-  else if (mask == M_Q5K) hipLaunchKernelGGL((mv_kernel<M_Q5K, 512>), grid, block, 0, st, L);
-  else if (mask == M_Q6K) hipLaunchKernelGGL((mv_kernel<M_Q6K, 512>), grid, block, 0, st, L);
-  else if (mask == (M_Q4K | M_Q6K)) hipLaunchKernelGGL((mv_kernel<M_Q4K | M_Q6K, 512>), grid, block, 0, st, L);
-  else if (mask == (M_Q5K | M_Q6K)) hipLaunchKernelGGL((mv_kernel<M_Q5K | M_Q6K, 512>), grid, block, 0, st, L);
-  else hipLaunchKernelGGL((mv_kernel<M_ALL, 512>), grid, block, 0, st, L);
-  return hipGetLastError();
+  const size_t lds = ((size_t)L.k + L.red_floats + 16) * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (mask == M_Q4K) return mv_go<M_Q4K, 1024>(L, n_wg, threads, lds, st);
+  if (mask == M_Q80) return mv_go<M_Q80, 1024>(L, n_wg, threads, lds, st);
+  if (mask == M_Q40) return mv_go<M_Q40, 1024>(L, n_wg, threads, lds, st);
+  if (mask == M_Q5K) return mv_go<M_Q5K, 768>(L, n_wg, threads, lds, st);
+  if (mask == M_Q6K) return mv_go<M_Q6K, 512>(L, n_wg, threads, lds, st);
+  if (mask == (M_Q4K | M_Q6K)) return mv_go<M_Q4K | M_Q6K, 512>(L, n_wg, threads, lds, st);
+  if (mask == (M_Q5K | M_Q6K)) return mv_go<M_Q5K | M_Q6K, 512>(L, n_wg, threads, lds, st);
+  return mv_go<M_ALL, 512>(L, n_wg, threads, lds, st);
 }
 
 // ------------------------------------------------------------------------------------------ F32

@@ -1,0 +1,82 @@
+// mv_epilogue.h — per-row epilogues shared by the VALU and the int8-MFMA mat-vec kernels (internal).
+#pragma once
+
+#include "device_utils.h"
+
+namespace lgh {
+
+__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
+
+// Per-row epilogue, one thread per row (or per row pair for RoPE)
+// `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
+__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
+                                            const float* ssq, uint32_t nslots) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t rbase = wg * S.rows_per_wg;
+  float inv = 1.0f;
+  if (L.do_norm) {  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
+    float tot = 0.0f;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); w++) tot += ssq[w];
+    inv = 1.0f / __builtin_sqrtf(tot / (float)L.k + L.eps);
+  }
+  auto rowval = [&](int p, uint32_t rl) {
+    float v = 0.0f;
+    for (uint32_t ks = 0; ks < nslots; ks++) v += red[(size_t)(p * nslots + ks) * S.rows_per_wg + rl];
+    return v * inv;
+  };
+  if (S.epi == EPI_ROPE_Q || S.epi == EPI_ROPE_K) {
+    uint32_t rl = 2 * t, row = rbase + rl;
+    if (rl >= S.rows_per_wg || row >= S.n_rows) return;
+    float x0 = rowval(0, rl), x1 = rowval(0, rl + 1);
+    if (S.bias) { x0 += S.bias[row]; x1 += S.bias[row + 1]; }
+    const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim, half = d / 2;
+    const uint32_t head = row / d, i = (row % d) / 2;
+    const float c = L.rope_cs[((size_t)pos * half + i) * 2], s = L.rope_cs[((size_t)pos * half + i) * 2 + 1];
+    float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
+    if (S.epi == EPI_ROPE_Q) {
+      S.out[row] = y0;
+      S.out[row + 1] = y1;
+    } else {
+      float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
+      dst[0] = y0;
+      dst[1] = y1;
+    }
+    return;
+  }
+  if (t >= S.rows_per_wg) return;
+  const uint32_t row = rbase + t;
+  if (row >= S.n_rows) return;
+  float v0 = rowval(0, t);
+  if (S.bias) v0 += S.bias[row];
+  switch (S.epi) {
+    case EPI_STORE: S.out[row] = v0; break;
+    case EPI_RESID: S.out[row] = v0 + S.resid[row]; break;
+    case EPI_SWIGLU: {
+      float up = rowval(1, t);
+      S.out[row] = silu_f(v0) * up;
+      break;
+    }
+    case EPI_V_CACHE: {
+      const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
+      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
+      break;
+    }
+    case EPI_MOE_SWIGLU: {
+      for (int e = 0; 2 * e + 1 < S.npass; e++) {
+        float g = rowval(2 * e, t), up = rowval(2 * e + 1, t);
+        float* o = e == 0 ? S.out : S.out2;
+        o[row] = silu_f(g) * up;
+      }
+      break;
+    }
+    case EPI_MOE_DOWN: {
+      float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
+      for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
+      S.out[row] = acc + S.resid[row];
+      break;
+    }
+    default: break;
+  }
+}
+
+}  // namespace lgh

@@ -10,7 +10,7 @@
 using namespace lgh;
 
 #ifdef LGH_STAMPS
-namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); }
+namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); }
 #include <algorithm>
 #include <cstdio>
 #endif
@@ -235,15 +235,16 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
 #ifdef LGH_STAMPS
   {  // phase profile of the LAST launch: per stamp, min / median / max over workgroups, relative to the first start
     std::vector<unsigned long long> st(8192 * 8);
-    if (lgh::mv_read_stamps(st.data(), st.size()) == hipSuccess) {
+    if ((Ws[0].type == kDevQ4K_T16 ? lgh::mvq_read_stamps(st.data(), st.size()) : lgh::mv_read_stamps(st.data(), st.size())) == hipSuccess) {
       MvPlan plan;
-      (void)mv_plan(Ws[0].type, (uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n);
+      if (Ws[0].type == kDevQ4K_T16) (void)mvq_plan((uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n);
+      else (void)mv_plan(Ws[0].type, (uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n, 0);
       size_t nwg = std::min<size_t>(plan.n_wg, 8192);
       unsigned long long t0 = ~0ull;
       for (size_t w = 0; w < nwg; w++) t0 = std::min(t0, st[w * 8]);
       std::fprintf(stderr, "  stamps (us since first workgroup start; %zu workgroups x %u threads, rows/wg %u):\n", nwg, plan.threads, plan.rows_per_wg);
-      const char* names[6] = {"start", "x ready", "first item done", "stream done", "after barrier", "end"};
-      for (int i = 0; i < 6; i++) {
+      const char* names[8] = {"start", "x published", "first item done", "stream done", "after barrier", "end", "loads issued", "x staged"};
+      for (int i = 0; i < 8; i++) {
         std::vector<double> v;
         for (size_t w = 0; w < nwg; w++) v.push_back((double)(st[w * 8 + i] - t0) / 100.0);
         std::sort(v.begin(), v.end());

@@ -177,7 +177,8 @@ def test_profiling_stats(pkg, orc):
     eng.set_profiling(False)
     st = eng.stats()
     k = st["kernels"]
-    assert k["qkv"]["launches"] == cfg.num_layers and k["gate_up"]["launches"] == cfg.num_layers
+    # a QKV launch splits in two when V is Q6_K (VALU kernel) while Q and K are Q4_K (matrix-core kernel)
+    assert cfg.num_layers <= k["qkv"]["launches"] <= 2 * cfg.num_layers and k["gate_up"]["launches"] == cfg.num_layers
     assert k["output"]["launches"] == 1 and all(v["time_us"] > 0 for v in k.values())
     model = pkg.SynthModel(cfg, mix="Q4_K_M")
     assert abs(st["step_alg_bytes"] - model.step_alg_bytes(eng.position() + 1)) <= 0.01 * st["step_alg_bytes"]
