@@ -19,12 +19,28 @@ import json
 import os
 import sys
 import time
+from pathlib import Path
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft  # noqa: E402
+
+# HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE,
+# guides/MI355X_MICROARCH.md "HBM traffic"), which cannot be collected from inside this process: tools/gpu_measure.sh
+# runs them on the same command and tools/summarize_profiles.py commits the per-kernel table under profiles/.  The
+# newest committed table is what `roofline.traffic` reports (with its file name), null when there is none.
+def committed_traffic(kernel):
+    import csv
+    tables = sorted((Path(__file__).resolve().parent / "profiles").glob("*_pmc_traffic.csv"))
+    for t in reversed(tables):
+        with open(t, newline="") as f:
+            for row in csv.DictReader(f):
+                if row["kernel"] == kernel and int(row["launches_fetch_pass"]) > 0:
+                    return int(float(row["hbm_bytes_per_launch_corrected"])), t.name
+    return None, None
+
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 
@@ -51,7 +67,8 @@ def cpu_baseline(pkg, model, cfg, budget_s: float):
     """The oracle (a C++ port of the reference CPU backend's arithmetic) timed on this host's cores, on a
     bounded sample of the same workload: same weights, short prefill, a few decode tokens."""
     orc = graft.load_oracle()
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)                     # the GPU box gives one GPU's share of the host: 16 cores
     orc.set_threads(cores)
     ref = orc.Model(cfg.as_dict())
     for name, t, ne, data in model.tensors(keep=True):
@@ -133,12 +150,19 @@ def run_single(args, pkg):
         syms = st["symbols"]
         dom = max(syms, key=lambda s: syms[s]["time_us"])
         d = syms[dom]
-        avg_us = d["time_us"] / d["launches"]
+        # A hipEvent pair around ONE launch also times the bracket itself (event packets + dispatch latency on an
+        # otherwise drained queue).  That fixed cost is measured live with an empty bracket on the same stream and
+        # removed, which is what makes this figure agree with rocprofv3's per-kernel average (profiles/).
+        bracket_us = st["event_bracket_us"]
+        raw_us = d["time_us"] / d["launches"]
+        avg_us = max(raw_us - bracket_us, 1e-3)
         bytes_per_launch = d["alg_bytes"] / d["launches"]
         achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+        traffic, traffic_src = committed_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": d["launches"] / P, "avg_launch_us": round(avg_us, 3),
+                    "avg_launch_us_with_event_bracket": round(raw_us, 3), "event_bracket_us": round(bracket_us, 3),
                     "alg_bytes_per_launch": int(bytes_per_launch)}
         tot = sum(v["time_us"] for v in syms.values())
         kernels = {s: {"launches_per_step": v["launches"] / P, "avg_us": round(v["time_us"] / v["launches"], 3),

@@ -135,6 +135,10 @@ typedef struct lgh_stats {
   uint64_t sym_alg_bytes[LGH_SYM_COUNT];
   /* algorithmic bytes of one decode step at the current position (SURVEY.md §8d formula) */
   uint64_t step_alg_bytes;
+  /* profiling mode: mean elapsed time of an EMPTY hipEvent bracket on the launch stream, measured once per
+   * profiled token — the fixed cost every k_time_us / sym_time_us sample carries on top of the kernel itself */
+  double event_bracket_us;
+  uint64_t event_bracket_samples;
 } lgh_stats;
 
 /* ---- lifecycle: replaces GpuOnlyInference::from_model (src/backend/cuda/gpu_only.rs:426-726) ---- */

@@ -172,7 +172,11 @@ int drain_prof(lgh_ctx* c) {
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   for (auto& r : c->prof) {
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.cls < 0) {
+      const double n = (double)c->stats.event_bracket_samples;
+      c->stats.event_bracket_us = (c->stats.event_bracket_us * n + (double)ms * 1000.0) / (n + 1.0);
+      c->stats.event_bracket_samples += 1;
+    } else if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       c->stats.k_time_us[r.cls] += (double)ms * 1000.0;
       c->stats.k_launches[r.cls] += 1;
       c->stats.k_alg_bytes[r.cls] += r.bytes;
@@ -380,6 +384,9 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
 static int enqueue_token(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   int rc;
+  if (c->profiling) {  // an empty event bracket: what the measurement itself costs on this stream
+    if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
+  }
   if (c->first) {
     if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
            return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, c->stream);
@@ -800,6 +807,8 @@ int lgh_set_profiling(lgh_ctx* c, int on) {
     std::memset(c->stats.sym_launches, 0, sizeof(c->stats.sym_launches));
     std::memset(c->stats.sym_time_us, 0, sizeof(c->stats.sym_time_us));
     std::memset(c->stats.sym_alg_bytes, 0, sizeof(c->stats.sym_alg_bytes));
+    c->stats.event_bracket_us = 0.0;
+    c->stats.event_bracket_samples = 0;
   }
   return LGH_OK;
 }

@@ -42,7 +42,7 @@ hipError_t mvq_read_stamps(unsigned long long* host, size_t n) {
 #endif
 
 constexpr int kTileBytes = 2304;
-constexpr int kStageBlocks = 2;  // x blocks a wave keeps in flight while staging
+constexpr int kStageBlocks = 1;  // x blocks a wave keeps in flight while staging
 
 // ------------------------------------------------------------------------------------------------
 // native [row][block] Q4_K  ->  tile16
@@ -100,22 +100,21 @@ __device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane
   uint32_t e = (__float_as_uint(amax) >> 23) & 0xFFu;       // biased exponent: amax in [2^(e-127), 2^(e-126))
   e = e < 30u ? 30u : (e > 250u ? 250u : e);                 // vanishing / overflowing blocks: clamp (|x'| stays < 1)
   const float inv_s = __uint_as_float((253u - e) << 23);     // 2^-(e-126): x' = x * inv_s in (-1, 1)
-  const float xe[4] = {v.x, v.y, v.z, v.w};
-  int l[4][4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {  // every step is exact in f32 (power-of-two scaling, subtraction of a nearby integer)
-    float y = xe[k] * inv_s * 64.0f;
-    float r = __builtin_rintf(y);
-    l[0][k] = (int)r;
-    y = (y - r) * 128.0f; r = __builtin_rintf(y); l[1][k] = (int)r;
-    y = (y - r) * 128.0f; r = __builtin_rintf(y); l[2][k] = (int)r;
-    y = (y - r) * 128.0f; r = __builtin_rintf(y); l[3][k] = (int)r;
-  }
+  // limb-major: only the four residuals stay live.  Every step is exact in f32 (power-of-two scaling, subtraction
+  // of a nearby integer).
+  float y[4] = {v.x * inv_s * 64.0f, v.y * inv_s * 64.0f, v.z * inv_s * 64.0f, v.w * inv_s * 64.0f};
   const uint32_t g = lane >> 3, kin = (lane & 7) * 4;        // sub-block and offset inside it
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const uint32_t pk = (uint32_t)(l[i][0] & 0xFF) | ((uint32_t)(l[i][1] & 0xFF) << 8) | ((uint32_t)(l[i][2] & 0xFF) << 16) |
-                        ((uint32_t)l[i][3] << 24);
+    int li[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float r = __builtin_rintf(y[k]);
+      li[k] = (int)r;
+      y[k] = (y[k] - r) * 128.0f;
+    }
+    const uint32_t pk = (uint32_t)(li[0] & 0xFF) | ((uint32_t)(li[1] & 0xFF) << 8) | ((uint32_t)(li[2] & 0xFF) << 16) |
+                        ((uint32_t)li[3] << 24);
     *reinterpret_cast<uint32_t*>(limbs + ((size_t)(blk * 8 + g) * 4 + i) * 32 + kin) = pk;
   }
   float gs = (v.x + v.y) + (v.z + v.w);                      // f32 sum of the sub-block's x (reference: x_acc, simd.rs:1002-1008)
@@ -199,11 +198,11 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
     ip = (uint32_t)p0; itl = 0; ib = 0;
     uint32_t ap = 0, atl = 0, ab = 0, bp = 0, btl = 0, bb = 0;
     float ss = 0.0f;
-    bool first_issued = false;
+    // pass 1: x (an L2 / Infinity-Cache hit) is requested BEFORE the first weight tile — loads return in order, so
+    // the staging waits only for x while the HBM-latency weight loads stay in flight behind it — scaled by the norm
+    // weight and parked as f32 in the block's own 1-KiB LDS region
     for (uint32_t cb0 = wave; cb0 < nblk_all; cb0 += nwaves * kStageBlocks) {
       f32x4 xv[kStageBlocks], wv[kStageBlocks];
-      // x (an L2 / Infinity-Cache hit) is requested BEFORE the first weight tile: loads return in order, so the
-      // staging below waits only for x while the HBM-latency weight loads stay in flight behind it
 #pragma unroll
       for (int j = 0; j < kStageBlocks; j++) {
         const uint32_t cb = cb0 + j * nwaves;
@@ -216,7 +215,6 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
           if (cb < nblk_all) wv[j] = reinterpret_cast<const f32x4*>(L.norm_w)[cb * 64 + lane];
         }
       }
-      if (!first_issued && has_work) { first_issued = true; ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance(); }
       LGH_STAMP(6);
 #pragma unroll
       for (int j = 0; j < kStageBlocks; j++) {
@@ -230,11 +228,19 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
             ss = __builtin_fmaf(v.w, v.w, ss);
             v = v * wv[j];
           }
-          stage_block(v, cb, lane, limbs, xsum, sxs);
+          *reinterpret_cast<f32x4*>(limbs + (size_t)cb * 1024 + lane * 16) = v;
         }
       }
     }
-    if (!first_issued && has_work) { ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance(); }
+    // the first weight tile goes out here: behind x in the load queue, ahead of the limb arithmetic and the barrier
+    // (issuing it before pass 1 costs 20 live registers there and spills at the 128-VGPR budget of 16-wave workgroups)
+    if (has_work) { ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance(); }
+    // pass 2: each wave turns ITS blocks into limbs in place (same wave wrote the floats; reads complete before the
+    // limb stores are issued, and no other wave touches the region)
+    for (uint32_t cb = wave; cb < nblk_all; cb += nwaves) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(limbs + (size_t)cb * 1024 + lane * 16);
+      stage_block(v, cb, lane, limbs, xsum, sxs);   // LDS ops of one wave execute in order: the read above precedes the stores
+    }
     if (nrm && p0 == 0) {
       ss = wave_sum_to_lane63(ss);
       if (lane == 63) ssq[wave] = ss;

@@ -68,7 +68,8 @@ class Stats(C.Structure):
                 ("k_launches", C.c_uint64 * K_COUNT), ("k_time_us", C.c_double * K_COUNT),
                 ("k_alg_bytes", C.c_uint64 * K_COUNT),
                 ("sym_launches", C.c_uint64 * K_COUNT), ("sym_time_us", C.c_double * K_COUNT),
-                ("sym_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64)]
+                ("sym_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64),
+                ("event_bracket_us", C.c_double), ("event_bracket_samples", C.c_uint64)]
 
 
 _lib = None
@@ -239,7 +240,7 @@ class HipGpuInference:
         s = Stats()
         self._call(load_library().lgh_get_stats(self._h, C.byref(s)))
         out = {k: getattr(s, k) for k in ("weight_bytes", "kv_bytes", "scratch_bytes", "tokens_processed",
-                                          "graph_nodes", "step_alg_bytes")}
+                                          "graph_nodes", "step_alg_bytes", "event_bracket_us")}
         out["kernels"] = {K_NAMES[i]: {"launches": s.k_launches[i], "time_us": s.k_time_us[i],
                                        "alg_bytes": s.k_alg_bytes[i]}
                           for i in range(len(K_NAMES)) if s.k_launches[i]}

@@ -183,3 +183,31 @@ def test_profiling_stats(pkg, orc):
     model = pkg.SynthModel(cfg, mix="Q4_K_M")
     assert abs(st["step_alg_bytes"] - model.step_alg_bytes(eng.position() + 1)) <= 0.01 * st["step_alg_bytes"]
     eng.close()
+
+
+def test_cpp_host_mirror(pkg, orc, tmp_path):
+    """The C++ mirror of GpuInference / GpuModelWrapper (llama-gguf_amd/host/hip_gpu_inference.hpp), compiled with g++
+    against the C-ABI libraries, gives the oracle's logits and greedy tokens."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "llama-gguf_amd", "lib")
+    exe = str(tmp_path / "host_mirror_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "cpp", "host_mirror_test.cpp"), "-o", exe,
+                    "-L" + lib, "-lllama_gguf_hip", "-lllama_gguf_synth", "-Wl,-rpath," + lib], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    cfg = pkg.make_config("test-dense", max_seq_len=32)
+    model = pkg.SynthModel(cfg, mix="Q4_K")
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    toks = [3, 17, 255, 9, 700]
+    for step in range(4):
+        head, vals = out[step].split(":")
+        got = np.array([float.fromhex(v) for v in vals.split()], dtype=np.float32)
+        want = ref.forward(toks)
+        assert np.abs(got - want).max() <= _tol(want)
+        assert int(head.split()[-1]) == orc.argmax_last(want) == orc.argmax_last(got)
+        toks = [orc.argmax_last(want)]
+    assert out[4] == "error-variant InvalidArgument"
