@@ -8,15 +8,16 @@
 // 32-group `sum(q*x)` and `sum(x)` are accumulated and the f16 scales applied once per group.
 //
 // Design for CDNA4 (HBM-bound, 3.5 flop/B):
-//   * weights are the only streamed operand: each lane issues 16-byte non-temporal loads straight to
-//     VGPRs (no LDS round trip), B rows deep, so a wave keeps B KiB in flight;
-//   * a lane owns a fixed 32/64-element slice of K ("unit") for the whole kernel, so its slice of x
-//     (and the per-16 sums of x used by the min/offset terms) live in registers and cost nothing per row;
-//   * a row of K elements is covered by T = ceil(units/64) waves of one workgroup (k-slices); partial
-//     sums meet in LDS once, at the end of the workgroup;
-//   * RMSNorm is a prologue (every workgroup re-derives the 1/rms from the L2-resident x), and
-//     residual add / SwiGLU / RoPE + KV-cache write / MoE expert mixing are epilogues, so a dense
-//     layer is 5 launches instead of the reference's ~20.
+//   * ONE workgroup per CU (grid ~ 256); its waves are T k-slices x G row-groups.  x is loaded and (with the
+//     RMSNorm prologue) scaled by the norm weight ONCE per workgroup and staged through LDS; every wave then
+//     keeps its k-slice of x (and the per-16 sums used by the min/offset terms) in registers for the whole kernel;
+//   * weights are the only streamed operand: each lane issues 16-byte non-temporal loads straight to VGPRs,
+//     software-pipelined in double-buffered batches of B rows with static load counts (no LDS round trip);
+//   * partial sums of the k-slices meet in LDS once, at the end of the workgroup;
+//   * the mat-vec is linear in x, so the RMSNorm factor 1/rms is applied per output row in the epilogue; residual
+//     add / SwiGLU / RoPE + KV-cache write / MoE expert mixing are epilogues too (mv_epilogue.h), so a dense layer
+//     is 6 launches instead of the reference's ~20.
+// Q4_K launches go to the MFMA kernel (matvec_mfma.hip); this kernel serves Q5_K, Q6_K, Q8_0, Q4_0 and mixed launches.
 #include "device_utils.h"
 #include "mv_epilogue.h"
 
