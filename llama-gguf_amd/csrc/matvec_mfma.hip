@@ -13,8 +13,8 @@
 // power-of-two block scale,  x = s * (l1*2^-6 + l2*2^-13 + l3*2^-20 + l4*2^-27),  |residual| <= 2^-28 * s.
 // The limbs are the A operand (rows 0-3 = group 2p, rows 4-7 = group 2p+1 of a block-diagonal 16x64 tile), 16
 // weight rows x 64 nibbles are the B operand, and D holds sum_k q_k*l_i,k as exact int32.  Per 32-element
-// sub-block the four limb sums are recombined in f32 (V = D0*2^21 + D1*2^14 + D2*2^7 + D3) and scaled by
-// d*sc*s*2^-27; the min term uses f32 sums of x per sub-block, exactly as the reference's x_acc.
+// sub-block the four limb sums are recombined in f32 (V = D0*2^24 + D1*2^16 + D2*2^8 + D3) and scaled by
+// d*sc*s*2^-30; the min term uses f32 sums of x per sub-block, exactly as the reference's x_acc.
 // Error vs the reference's sequential f32 sum is below f32 rounding noise and independent of summation order.
 //
 // Device layout "tile16" (same bytes as GGUF, rows padded to 16): a tile = 16 rows x one 256-element block =
@@ -37,8 +37,19 @@ hipError_t mvq_read_stamps(unsigned long long* host, size_t n) {
   do {                                                                                           \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
+// per-WAVE stamps (slot 0 = wave start, 1 = x staged, before the barrier): how far apart the waves of a workgroup run
+__device__ unsigned long long g_wstamps[2048 * 16 * 2];
+hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wstamps), n * sizeof(unsigned long long));
+}
+#define LGH_WSTAMP(i)                                                                            \
+  do {                                                                                           \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                            \
+      g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define LGH_STAMP(i)
+#define LGH_WSTAMP(i)
 #endif
 
 constexpr int kTileBytes = 2304;
@@ -99,30 +110,34 @@ __device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane
   const float amax = wave_max_all(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   uint32_t e = (__float_as_uint(amax) >> 23) & 0xFFu;       // biased exponent: amax in [2^(e-127), 2^(e-126))
   e = e < 30u ? 30u : (e > 250u ? 250u : e);                 // vanishing / overflowing blocks: clamp (|x'| stays < 1)
-  const float inv_s = __uint_as_float((253u - e) << 23);     // 2^-(e-126): x' = x * inv_s in (-1, 1)
-  // limb-major: only the four residuals stay live.  Every step is exact in f32 (power-of-two scaling, subtraction
-  // of a nearby integer).
-  float y[4] = {v.x * inv_s * 64.0f, v.y * inv_s * 64.0f, v.z * inv_s * 64.0f, v.w * inv_s * 64.0f};
+  // x' = x * 2^-(e-126) lies in (-1, 1); I = rint(x' * 2^30) is an int32 with |I| <= 2^30.  Balanced base-256 digits
+  // of I (each in [-128, 127], top digit in [-64, 64]) are the four int8 limbs:  adding 0x00808080 biases the three low
+  // bytes by +128 with the carries landing where they belong, and the XOR takes the bias back out byte-wise
+  // (u - 128 as a signed byte is u ^ 0x80).  I = d3*2^24 + d2*2^16 + d1*2^8 + d0 exactly.
+  const float sc30 = __uint_as_float((283u - e) << 23);      // 2^-(e-126) * 2^30
+  uint32_t w[4];
+  const float xin[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int I = (int)__builtin_rintf(xin[k] * sc30);
+    w[k] = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;
+  }
+  // 4x4 byte transpose: element-major words -> one word per limb holding this lane's 4 consecutive elements
+  const uint32_t t0 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), t1 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
+  const uint32_t u0 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), u1 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
+  const uint32_t limb[4] = {__builtin_amdgcn_perm(u1, t1, 0x07060302u),    // d3: most significant, limb row 0
+                            __builtin_amdgcn_perm(u1, t1, 0x05040100u),    // d2
+                            __builtin_amdgcn_perm(u0, t0, 0x07060302u),    // d1
+                            __builtin_amdgcn_perm(u0, t0, 0x05040100u)};   // d0
   const uint32_t g = lane >> 3, kin = (lane & 7) * 4;        // sub-block and offset inside it
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int li[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const float r = __builtin_rintf(y[k]);
-      li[k] = (int)r;
-      y[k] = (y[k] - r) * 128.0f;
-    }
-    const uint32_t pk = (uint32_t)(li[0] & 0xFF) | ((uint32_t)(li[1] & 0xFF) << 8) | ((uint32_t)(li[2] & 0xFF) << 16) |
-                        ((uint32_t)li[3] << 24);
-    *reinterpret_cast<uint32_t*>(limbs + ((size_t)(blk * 8 + g) * 4 + i) * 32 + kin) = pk;
-  }
+  for (int i = 0; i < 4; i++) *reinterpret_cast<uint32_t*>(limbs + ((size_t)(blk * 8 + g) * 4 + i) * 32 + kin) = limb[i];
   float gs = (v.x + v.y) + (v.z + v.w);                      // f32 sum of the sub-block's x (reference: x_acc, simd.rs:1002-1008)
   gs += dpp_f<0xB1>(gs);
   gs += dpp_f<0x4E>(gs);
   gs += dpp_f<0x141>(gs);                                    // row_half_mirror: the 8 lanes of a sub-block
   if ((lane & 7) == 0) xsum[(blk * 2 + (g & 1)) * 4 + (g >> 1)] = gs;   // layout [blk][mq = g&1][p = g>>1]
-  if (lane == 0) sxs[blk] = __uint_as_float((e + 1u - 27u) << 23);      // s * 2^-27,  s = 2^(e-126)
+  if (lane == 0) sxs[blk] = __uint_as_float((e + 1u - 30u) << 23);      // s * 2^-30,  s = 2^(e-126)
 }
 
 template <int MAXT>
@@ -130,6 +145,7 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   const uint32_t K = L.k, nblk_all = K >> 8;
   int8_t* limbs = reinterpret_cast<int8_t*>(smem8);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
   float* xsum = reinterpret_cast<float*>(smem8 + (size_t)K * 4);
   float* sxs = xsum + (K >> 5);
   float* red = sxs + ((nblk_all + 3) & ~3u);
@@ -173,7 +189,11 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
 
   auto issue = [&](uint32_t p, uint32_t tl, uint32_t b, RawT16& r) {
     const MvPass& P = S.pass[p];
-    const uint64_t e = P.sel ? (uint64_t)(uint32_t)(*P.sel) : 0;
+    // MoE expert index: a SCALAR load (its own counter) — a vector load here would make the address computation wait
+    // on vmcnt(0), i.e. on every x DMA and weight tile still in flight
+    uint32_t e32 = 0;
+    if (P.sel) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(P.sel) : "memory");
+    const uint64_t e = e32;
     const uint8_t* tile = P.plane[0] + e * P.sel_stride[0] + ((size_t)(tile0 + tl) * S_nblk + (blk0 + b)) * kTileBytes;
     r.hd = ldg_nt128(tile + lane_off_hd);
 #pragma unroll
@@ -182,6 +202,7 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
 
   RawT16 A, Bq;
   LGH_STAMP(0);
+  LGH_WSTAMP(0);
   // item order: pass-major, then tile, then block (innermost: one accumulator per (pass, tile))
   uint32_t ip = 0, itl = 0, ib = 0;
   auto advance = [&]() {
@@ -201,6 +222,18 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
     // pass 1: x (an L2 / Infinity-Cache hit) is requested BEFORE the first weight tile — loads return in order, so
     // the staging waits only for x while the HBM-latency weight loads stay in flight behind it — scaled by the norm
     // weight and parked as f32 in the block's own 1-KiB LDS region
+    if (!nrm) {
+      // plain input: LDS-DMA, 1 KiB per wave-instruction straight into the block's region — no registers, so every
+      // block of this wave is requested back to back instead of one L2 round trip at a time
+      // (inline asm: hipcc drains vmcnt to 0 before the next load it issues while a DMA it knows about is in flight)
+      for (uint32_t cb = wave; cb < nblk_all; cb += nwaves) {
+        const float* src = xg + (size_t)cb * 256 + lane * 4;
+        const uint32_t dst = lds_base + cb * 1024;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+    } else {
     for (uint32_t cb0 = wave; cb0 < nblk_all; cb0 += nwaves * kStageBlocks) {
       f32x4 xv[kStageBlocks], wv[kStageBlocks];
 #pragma unroll
@@ -232,9 +265,15 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
         }
       }
     }
+    }
     // the first weight tile goes out here: behind x in the load queue, ahead of the limb arithmetic and the barrier
     // (issuing it before pass 1 costs 20 live registers there and spills at the 128-VGPR budget of 16-wave workgroups)
-    if (has_work) { ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance(); }
+    if (has_work) {
+      ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance();
+      if (!nrm) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // the x DMAs precede the tile's 5 loads in the queue
+    } else if (!nrm) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // pass 2: each wave turns ITS blocks into limbs in place (same wave wrote the floats; reads complete before the
     // limb stores are issued, and no other wave touches the region)
     for (uint32_t cb = wave; cb < nblk_all; cb += nwaves) {
@@ -246,6 +285,7 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
       if (lane == 63) ssq[wave] = ss;
     }
     LGH_STAMP(7);
+    LGH_WSTAMP(1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // publish x; weight loads stay in flight
     LGH_STAMP(1);
     if (!has_work) { p0 = p1; continue; }
@@ -287,9 +327,10 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
         bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
         const i32x4 zero = {0, 0, 0, 0};
         const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
-        // lanes mq<2: d = limb sums of sub-block 2pp+mq for row n.  V = D0*2^21 + D1*2^14 + D2*2^7 + D3
-        const float hi = (float)((d.x << 7) + d.y), lo = (float)((d.z << 7) + d.w);
-        const float V = __builtin_fmaf(hi, 16384.0f, lo);
+        // lanes mq<2: d = limb sums of sub-block 2pp+mq for row n.  V = D0*2^24 + D1*2^16 + D2*2^8 + D3; both halves
+        // are exact in f32 (|D0| <= 64*480, |D1..3| <= 128*480, so |(Da<<8)+Db| < 2^24)
+        const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+        const float V = __builtin_fmaf(hi, 65536.0f, lo);
         s1 = __builtin_fmaf(scf[pp], V, s1);
         s2 = __builtin_fmaf(mnf[pp], xs4[pp], s2);
       }
@@ -323,7 +364,7 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
       bp = ip; btl = itl; bb = ib; issue(ip, itl, ib, Bq);
       consume(ap, atl, ab, A);
       consume(bp, btl, bb, Bq);
-    } else if (remaining == 1) {
+    } else {   // remaining == 1
       consume(ap, atl, ab, A);
     }
     p0 = p1;

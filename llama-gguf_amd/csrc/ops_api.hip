@@ -10,7 +10,7 @@
 using namespace lgh;
 
 #ifdef LGH_STAMPS
-namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); }
+namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); }
 #include <algorithm>
 #include <cstdio>
 #endif
@@ -249,6 +249,22 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
         for (size_t w = 0; w < nwg; w++) v.push_back((double)(st[w * 8 + i] - t0) / 100.0);
         std::sort(v.begin(), v.end());
         std::fprintf(stderr, "    %-16s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[i], v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+      }
+      if (Ws[0].type == kDevQ4K_T16) {
+        std::vector<unsigned long long> ws(2048 * 16 * 2);
+        if (lgh::mvq_read_wave_stamps(ws.data(), ws.size()) == hipSuccess) {
+          const size_t nw = plan.threads / 64, ng = std::min<size_t>(nwg, 2048);
+          for (int i = 0; i < 2; i++) {
+            std::fprintf(stderr, "    per-wave %-8s p50:", i == 0 ? "start" : "staged");
+            for (size_t w = 0; w < nw; w++) {
+              std::vector<double> v;
+              for (size_t g = 0; g < ng; g++) v.push_back((double)(ws[(g * 16 + w) * 2 + i] - t0) / 100.0);
+              std::sort(v.begin(), v.end());
+              std::fprintf(stderr, " %5.2f", v[v.size() / 2]);
+            }
+            std::fprintf(stderr, "\n");
+          }
+        }
       }
     }
   }
