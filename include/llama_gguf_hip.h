@@ -115,7 +115,7 @@ enum {
   LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
   LGH_SYM_ROUTER = 13,
   LGH_SYM_OTHER = 14,
-  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1024> : Q4_K mat-vec on the int8 matrix cores */
+  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel : Q4_K mat-vec on the int8 matrix cores */
   LGH_SYM_COUNT = 16
 };
 

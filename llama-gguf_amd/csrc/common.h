@@ -127,6 +127,7 @@ struct MvLaunch {
   const int* pos;            // device: current position (RoPE / cache epilogues)
   const float* rope_cs;      // [max_seq][head_dim/2][2] cos,sin
   uint32_t red_floats;       // LDS floats for per-row partial sums (max over segments)
+  uint32_t dbg_slot;         // diagnostic builds: launch sequence number mod 64 (span stamps)
   MvSeg seg[3];
 };
 

@@ -194,6 +194,7 @@ int drain_prof(lgh_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // fused mat-vec launch assembly
 // ------------------------------------------------------------------------------------------------
+static uint32_t g_launch_seq = 0;   // diagnostic builds: consecutive launches get consecutive span slots
 static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma) {
   MvLaunch L;
   std::memset(&L, 0, sizeof(L));
@@ -204,6 +205,7 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
   L.norm_w = norm_w;
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
+  L.dbg_slot = g_launch_seq++ & 63u;
   uint32_t wg = 0, threads = 0, launch_rows = 0;
   uint64_t alg = 0;
   uint32_t wave_cap = 16;

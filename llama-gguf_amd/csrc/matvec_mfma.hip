@@ -21,6 +21,8 @@
 // 2304 B:  [p=0..3][c'=0..1][row 0..15] 16-byte pieces qs_row[32p+16c' .. +16)  (2048 B), then the 16 native
 // 16-byte headers {d, dmin, scales[12]}.  Lane (n = l&15, c = l>>4) of a wave loads the piece (p, c&1, n): low
 // nibbles are sub-block 2p (c<2), high nibbles sub-block 2p+1 (c>=2), 16 consecutive elements each.
+#include <type_traits>
+
 #include "device_utils.h"
 #include "mv_epilogue.h"
 
@@ -37,23 +39,40 @@ hipError_t mvq_read_stamps(unsigned long long* host, size_t n) {
   do {                                                                                           \
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
-// per-WAVE stamps (slot 0 = wave start, 1 = x staged, before the barrier): how far apart the waves of a workgroup run
-__device__ unsigned long long g_wstamps[2048 * 16 * 2];
+// per-WAVE stamps (8 slots): how far apart the waves of a workgroup run and where a wave's prologue goes
+__device__ unsigned long long g_wstamps[2048 * 16 * 8];
 hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wstamps), n * sizeof(unsigned long long));
 }
+// first workgroup start / last workgroup end of each of the last 64 launches (slot = MvLaunch::dbg_slot)
+__device__ unsigned long long g_span[64 * 2];
+hipError_t mvq_spans(unsigned long long* host, int reset) {
+  if (reset) {
+    unsigned long long init[128];
+    for (int i = 0; i < 64; i++) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_span), init, sizeof(init));
+  }
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_span), 128 * sizeof(unsigned long long));
+}
+#define LGH_SPAN(i)                                                                              \
+  do {                                                                                           \
+    if (threadIdx.x == 0) {                                                                      \
+      if ((i) == 0) atomicMin(&g_span[L.dbg_slot * 2], (unsigned long long)__builtin_amdgcn_s_memrealtime()); \
+      else atomicMax(&g_span[L.dbg_slot * 2 + 1], (unsigned long long)__builtin_amdgcn_s_memrealtime()); \
+    }                                                                                            \
+  } while (0)
 #define LGH_WSTAMP(i)                                                                            \
   do {                                                                                           \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                            \
-      g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+      g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #else
 #define LGH_STAMP(i)
 #define LGH_WSTAMP(i)
+#define LGH_SPAN(i)
 #endif
 
 constexpr int kTileBytes = 2304;
-constexpr int kStageBlocks = 1;  // x blocks a wave keeps in flight while staging
 
 // ------------------------------------------------------------------------------------------------
 // native [row][block] Q4_K  ->  tile16
@@ -140,240 +159,276 @@ __device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane
   if (lane == 0) sxs[blk] = __uint_as_float((e + 1u - 30u) << 23);      // s * 2^-30,  s = 2^(e-126)
 }
 
-template <int MAXT>
-__global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  const uint32_t K = L.k, nblk_all = K >> 8;
-  int8_t* limbs = reinterpret_cast<int8_t*>(smem8);
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
-  float* xsum = reinterpret_cast<float*>(smem8 + (size_t)K * 4);
-  float* sxs = xsum + (K >> 5);
-  float* red = sxs + ((nblk_all + 3) & ~3u);
-  float* ssq = red + L.red_floats;
+constexpr int kWaves = 8;   // waves per workgroup: 2 per SIMD, 256 VGPRs each
+constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x 8 waves = 72 KiB per CU)
 
-  int s = 0;
+// Geometry: ONE workgroup per CU.  Its waves are T k-slices x G row-groups; wave (ks, rg) owns blocks
+// [ks*nbw, (ks+1)*nbw) of k for the Rg tiles of its row-group, i.e. a private stream of npass x Rg x nbw items
+// (item = one 16-row tile x one 256-element block = 2304 B).  Nothing is shared between waves until the final
+// reduction, so there is NO barrier on the way in: a wave requests its slice of x, puts up to kDepth weight tiles in
+// flight right behind it, converts x to limbs in its private LDS region while the tiles travel, and streams.  Few,
+// fat waves on purpose: the dispatcher starts the waves of a grid over ~1 us (measured: the 16 waves of a 1024-thread
+// workgroup began 0.25 / 0.33 / 0.67 / 1.05 us after launch, 4 at a time), which a barrier turns into idle time.
+__global__ void __launch_bounds__(kWaves * 64) mvq_kernel(const MvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  // Kernel arguments are read in TWO dependent rounds of scalar loads, each issued as one batch (a lazily loaded field
+  // costs its own ~0.2-0.4 us round trip, and there were five of them in a row before the first vector load):
+  // round 1 picks the segment, round 2 fetches everything the wave needs from it, for all four passes unconditionally.
   const uint32_t bid = blockIdx.x;
-  if (L.nseg > 1 && bid >= L.seg[1].wg_begin) s = 1;
-  if (L.nseg > 2 && bid >= L.seg[2].wg_begin) s = 2;
+  const int nseg = L.nseg;
+  const uint32_t wb1 = L.seg[1].wg_begin, wb2 = L.seg[2].wg_begin;
+  const int s = (int)(nseg > 1 && bid >= wb1) + (int)(nseg > 2 && bid >= wb2);
   const MvSeg& S = L.seg[s];
-  // every scalar the prologue needs, read up front so the s_loads go out together (each lazily loaded kernarg
-  // field used to cost a separate ~120 ns round trip: 1.1 us before the first vector load)
   const uint32_t S_T = S.T, S_G = S.G, S_units = S.units, S_nblk = S.nblk, S_rpw = S.rows_per_wg, S_nrows = S.n_rows;
   const int S_npass = S.npass;
-  const float* S_x0 = S.pass[0].x;
   const uint32_t wg = bid - S.wg_begin;
+  const uint8_t* P_plane[4] = {S.pass[0].plane[0], S.pass[1].plane[0], S.pass[2].plane[0], S.pass[3].plane[0]};
+  const float* P_x[4] = {S.pass[0].x, S.pass[1].x, S.pass[2].x, S.pass[3].x};
+  const int* P_sel[4] = {S.pass[0].sel, S.pass[1].sel, S.pass[2].sel, S.pass[3].sel};
+  const uint64_t P_stride[4] = {S.pass[0].sel_stride[0], S.pass[1].sel_stride[0], S.pass[2].sel_stride[0], S.pass[3].sel_stride[0]};
+  const float* L_norm_w = L.norm_w;
+  const uint32_t L_red_floats = L.red_floats;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
   const bool nrm = L.do_norm != 0;
-  for (uint32_t i = tid; i < L.red_floats; i += blockDim.x) red[i] = 0.0f;   // k-slices without blocks leave their slots untouched
-  // ---- this wave's share of the workgroup: k-slice ks (contiguous blocks), row-group rg (a run of tiles)
+  LGH_WSTAMP(0);
+  LGH_SPAN(0);
   const bool active = wave < S_T * S_G;
   const uint32_t ks = active ? wave % S_T : 0, rg = active ? wave / S_T : 0;
   const uint32_t nbw = S_units;                                   // blocks per k-slice
   const uint32_t blk0 = ks * nbw;
   const uint32_t nblk_w = active && blk0 < S_nblk ? min(nbw, S_nblk - blk0) : 0;
-  const uint32_t R = S_rpw >> 4, Rg = R / S_G;            // tiles per workgroup / per row-group
+  const uint32_t R = S_rpw >> 4, Rg = R / S_G;                    // tiles per workgroup / per row-group
   const uint32_t ntiles = (S_nrows + 15) >> 4;
   const uint32_t tile0 = wg * R + rg * Rg;
   const uint32_t ntile_w = active && tile0 < ntiles ? min(Rg, ntiles - tile0) : 0;
-  const bool has_work = nblk_w > 0 && ntile_w > 0;
+  // LDS: per-wave private limbs / sub-block sums / scales, then the partial-sum slots and the per-wave sum(x^2)
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
+  int8_t* limbs = reinterpret_cast<int8_t*>(smem8) + (size_t)wave * nbw * 1024;
+  const uint32_t limbs_lds = lds_base + wave * nbw * 1024;
+  float* xsum = reinterpret_cast<float*>(smem8 + (size_t)nwaves * nbw * 1024) + (size_t)wave * nbw * 8;
+  float* sxs = reinterpret_cast<float*>(smem8 + (size_t)nwaves * nbw * (1024 + 32)) + (size_t)wave * nbw;
+  float* red = reinterpret_cast<float*>(smem8 + (((size_t)nwaves * nbw * (1024 + 32 + 4) + 15) & ~(size_t)15));
+  float* ssq = red + L_red_floats;
   // lane roles inside an MFMA
   const uint32_t n = lane & 15, c = lane >> 4;                    // B: weight row n, k-chunk c; D: row n, limb quad mq = c
   const uint32_t sh = (c >> 1) * 4;                               // c>=2 lanes take the high nibbles
   const uint32_t lane_off_q = ((c & 1) * 16 + n) * 16, lane_off_hd = 2048 + n * 16;
   // A operand: rows m = lane&15: m<4 -> limb m of sub-block 2p (k-chunks 0,1); m in 4..7 -> limb m-4 of sub-block 2p+1
   const bool a_valid = n < 8 && (n >> 2) == (c >> 1);
-  const uint32_t a_off = ((c >> 1) * 4 + (n & 3)) * 32 + (c & 1) * 16;   // + (blk*8 + 2p) * 128
+  const uint32_t a_off = ((c >> 1) * 4 + (n & 3)) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
   const uint32_t mq = c;                                          // D lanes with mq < 2 hold sub-block 2p + mq
 
-  auto issue = [&](uint32_t p, uint32_t tl, uint32_t b, RawT16& r) {
-    const MvPass& P = S.pass[p];
-    // MoE expert index: a SCALAR load (its own counter) — a vector load here would make the address computation wait
-    // on vmcnt(0), i.e. on every x DMA and weight tile still in flight
+  // per-pass base of this wave's tiles, resolved once (scalar): the MoE expert index is a SCALAR load — a vector load
+  // would sit in the same in-order queue as the weight tiles
+  const uint8_t* pb[4] = {nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
     uint32_t e32 = 0;
-    if (P.sel) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(P.sel) : "memory");
-    const uint64_t e = e32;
-    const uint8_t* tile = P.plane[0] + e * P.sel_stride[0] + ((size_t)(tile0 + tl) * S_nblk + (blk0 + b)) * kTileBytes;
+    if (P_sel[p]) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(P_sel[p]) : "memory");
+    pb[p] = P_plane[p] + (uint64_t)e32 * P_stride[p] + ((size_t)tile0 * S_nblk + blk0) * kTileBytes;
+  }
+  LGH_WSTAMP(1);
+  struct Pos { uint32_t p, tl, b; };
+  auto issue = [&](const Pos& q, RawT16& r) {
+    const uint8_t* base = q.p == 0 ? pb[0] : q.p == 1 ? pb[1] : q.p == 2 ? pb[2] : pb[3];
+    const uint8_t* tile = base + ((size_t)q.tl * S_nblk + q.b) * kTileBytes;
     r.hd = ldg_nt128(tile + lane_off_hd);
 #pragma unroll
     for (int pp = 0; pp < 4; pp++) r.q[pp] = ldg_nt128(tile + pp * 512 + lane_off_q);
   };
 
-  RawT16 A, Bq;
   LGH_STAMP(0);
-  LGH_WSTAMP(0);
   // item order: pass-major, then tile, then block (innermost: one accumulator per (pass, tile))
-  uint32_t ip = 0, itl = 0, ib = 0;
+  Pos nx = {0, 0, 0};
   auto advance = [&]() {
-    if (++ib == nblk_w) { ib = 0; if (++itl == ntile_w) { itl = 0; ++ip; } }
+    if (++nx.b == nblk_w) { nx.b = 0; if (++nx.tl == ntile_w) { nx.tl = 0; ++nx.p; } }
+  };
+  float ss = 0.0f;   // sum of squares of this wave's slice of x (RMSNorm prologue; row-group 0 covers all of x)
+  float acc = 0.0f;
+
+  auto consume = [&](const Pos& q, const RawT16& r) {
+    // this block's x limbs, sub-block sums and scale: written by this same wave (LDS ops of a wave execute in order)
+    i32x4 areg[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      i32x4 t = {0, 0, 0, 0};
+      if (a_valid) t = *reinterpret_cast<const i32x4*>(limbs + (size_t)(q.b * 8 + 2 * pp) * 128 + a_off);
+      areg[pp] = t;
+    }
+    const f32x4 xs4 = *reinterpret_cast<const f32x4*>(xsum + (q.b * 2 + (mq & 1)) * 4);
+    const float sxb = sxs[q.b];
+    // 6-bit scales / mins of sub-blocks mq, mq+2, mq+4, mq+6 of row n (packing: dequant.rs:210-223)
+    const uint32_t s8 = (mq & 1) * 8;
+    const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
+    const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
+    const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
+    const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
+    const float scf[4] = {ub0(sc01), ub2(sc01), ub0(sc23), ub2(sc23)};
+    const float mnf[4] = {ub0(mn01), ub2(mn01), ub0(mn23), ub2(mn23)};
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      i32x4 bw;
+      bw.x = (int)((r.q[pp].x >> sh) & 0x0F0F0F0Fu);
+      bw.y = (int)((r.q[pp].y >> sh) & 0x0F0F0F0Fu);
+      bw.z = (int)((r.q[pp].z >> sh) & 0x0F0F0F0Fu);
+      bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
+      const i32x4 zero = {0, 0, 0, 0};
+      const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
+      // lanes mq<2: d = limb sums of sub-block 2pp+mq for row n.  V = D0*2^24 + D1*2^16 + D2*2^8 + D3; both halves
+      // are exact in f32 (|D0| <= 64*480, |D1..3| <= 128*480, so |(Da<<8)+Db| < 2^24)
+      const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+      const float V = __builtin_fmaf(hi, 65536.0f, lo);
+      s1 = __builtin_fmaf(scf[pp], V, s1);
+      s2 = __builtin_fmaf(mnf[pp], xs4[pp], s2);
+    }
+    const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
+    acc += (dd * sxb) * s1 - dmin * s2;
+    if (q.b + 1 == nblk_w) {   // last block of this (pass, tile): hand the partial sums to the epilogue
+      if (mq < 2) red[(size_t)(q.p * (2 * S_T) + ks * 2 + mq) * S_rpw + (rg * Rg + q.tl) * 16 + n] = acc;
+      acc = 0.0f;
+    }
   };
 
+  auto x_of = [&](int p) { return p == 0 ? P_x[0] : p == 1 ? P_x[1] : p == 2 ? P_x[2] : P_x[3]; };
   for (int p0 = 0; p0 < S_npass;) {   // phases: runs of passes that share one input vector
     int p1 = p0 + 1;
-    while (p1 < S_npass && S.pass[p1].x == S.pass[p0].x) p1++;
+    while (p1 < S_npass && x_of(p1) == x_of(p0)) p1++;
     const uint32_t npp = (uint32_t)(p1 - p0);
-    const float* xg = p0 == 0 ? S_x0 : S.pass[p0].x;
-    if (p0 > 0) __syncthreads();      // everyone is done reading the previous phase's limbs
-    // ---- stage x: block cb is handled by wave (cb % nwaves); the first weight tile is already in flight
-    ip = (uint32_t)p0; itl = 0; ib = 0;
-    uint32_t ap = 0, atl = 0, ab = 0, bp = 0, btl = 0, bb = 0;
-    float ss = 0.0f;
-    // pass 1: x (an L2 / Infinity-Cache hit) is requested BEFORE the first weight tile — loads return in order, so
-    // the staging waits only for x while the HBM-latency weight loads stay in flight behind it — scaled by the norm
-    // weight and parked as f32 in the block's own 1-KiB LDS region
-    if (!nrm) {
-      // plain input: LDS-DMA, 1 KiB per wave-instruction straight into the block's region — no registers, so every
-      // block of this wave is requested back to back instead of one L2 round trip at a time
-      // (inline asm: hipcc drains vmcnt to 0 before the next load it issues while a DMA it knows about is in flight)
-      for (uint32_t cb = wave; cb < nblk_all; cb += nwaves) {
-        const float* src = xg + (size_t)cb * 256 + lane * 4;
-        const uint32_t dst = lds_base + cb * 1024;
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-      }
-    } else {
-    for (uint32_t cb0 = wave; cb0 < nblk_all; cb0 += nwaves * kStageBlocks) {
-      f32x4 xv[kStageBlocks], wv[kStageBlocks];
-#pragma unroll
-      for (int j = 0; j < kStageBlocks; j++) {
-        const uint32_t cb = cb0 + j * nwaves;
-        if (cb < nblk_all) xv[j] = reinterpret_cast<const f32x4*>(xg)[cb * 64 + lane];
-      }
-      if (nrm) {
-#pragma unroll
-        for (int j = 0; j < kStageBlocks; j++) {
-          const uint32_t cb = cb0 + j * nwaves;
-          if (cb < nblk_all) wv[j] = reinterpret_cast<const f32x4*>(L.norm_w)[cb * 64 + lane];
-        }
-      }
-      LGH_STAMP(6);
-#pragma unroll
-      for (int j = 0; j < kStageBlocks; j++) {
-        const uint32_t cb = cb0 + j * nwaves;
-        if (cb < nblk_all) {   // wave-uniform
-          f32x4 v = xv[j];
-          if (nrm) {
-            ss = __builtin_fmaf(v.x, v.x, ss);
-            ss = __builtin_fmaf(v.y, v.y, ss);
-            ss = __builtin_fmaf(v.z, v.z, ss);
-            ss = __builtin_fmaf(v.w, v.w, ss);
-            v = v * wv[j];
-          }
-          *reinterpret_cast<f32x4*>(limbs + (size_t)cb * 1024 + lane * 16) = v;
-        }
-      }
-    }
-    }
-    // the first weight tile goes out here: behind x in the load queue, ahead of the limb arithmetic and the barrier
-    // (issuing it before pass 1 costs 20 live registers there and spills at the 128-VGPR budget of 16-wave workgroups)
-    if (has_work) {
-      ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance();
-      if (!nrm) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // the x DMAs precede the tile's 5 loads in the queue
-    } else if (!nrm) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // pass 2: each wave turns ITS blocks into limbs in place (same wave wrote the floats; reads complete before the
-    // limb stores are issued, and no other wave touches the region)
-    for (uint32_t cb = wave; cb < nblk_all; cb += nwaves) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(limbs + (size_t)cb * 1024 + lane * 16);
-      stage_block(v, cb, lane, limbs, xsum, sxs);   // LDS ops of one wave execute in order: the read above precedes the stores
-    }
-    if (nrm && p0 == 0) {
-      ss = wave_sum_to_lane63(ss);
-      if (lane == 63) ssq[wave] = ss;
-    }
-    LGH_STAMP(7);
-    LGH_WSTAMP(1);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // publish x; weight loads stay in flight
-    LGH_STAMP(1);
-    if (!has_work) { p0 = p1; continue; }
+    const float* xg = x_of(p0) + (size_t)blk0 * 256;   // this wave's k-slice
+    const float* nwg = L_norm_w + (size_t)blk0 * 256;
+    nx.p = (uint32_t)p0; nx.tl = 0; nx.b = 0;
+    const uint32_t nitems = npp * ntile_w * nblk_w;
 
-    // ---- stream
-    i32x4 areg[4];
-    f32x4 xs4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float sxb = 0.0f;
-    uint32_t cur_blk = 0xFFFFFFFFu;
-    float acc = 0.0f;
-    auto consume = [&](uint32_t p, uint32_t tl, uint32_t b, const RawT16& r) {
-      const uint32_t blk = blk0 + b;
-      if (blk != cur_blk) {   // wave-uniform: (re)load this block's x limbs, sub-block sums and scale
-        cur_blk = blk;
-#pragma unroll
-        for (int pp = 0; pp < 4; pp++) {
-          i32x4 t = {0, 0, 0, 0};
-          if (a_valid) t = *reinterpret_cast<const i32x4*>(limbs + (size_t)(blk * 8 + 2 * pp) * 128 + a_off);
-          areg[pp] = t;
+    // ---- x staging.  x_request goes out FIRST, the caller's tile issues right behind it; loads return in order, so
+    // x_finish waits for x alone (vmcnt = the weight loads behind it) and converts while the tiles are in flight.
+    f32x4 xv0, wv0, xv1, wv1;
+    const uint32_t b1 = nblk_w > 1 ? 1u : 0u;   // clamped, so the second request is unconditional (exact vmcnt bookkeeping)
+    auto x_request = [&]() {
+      if (!nrm) {
+        // plain input: LDS-DMA, 1 KiB per wave-instruction straight into the block's LDS region, no registers.
+        // (Inline asm: with the builtin hipcc drains vmcnt to 0 at the next load it issues.)
+        for (uint32_t b = 0; b < nblk_w; b++) {
+          const float* src = xg + b * 256 + lane * 4;
+          const uint32_t dst = limbs_lds + b * 1024;
+          uint32_t keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
-        xs4 = *reinterpret_cast<const f32x4*>(xsum + (blk * 2 + (mq & 1)) * 4);
-        sxb = sxs[blk];
+      } else {
+        xv0 = reinterpret_cast<const f32x4*>(xg)[lane];
+        wv0 = reinterpret_cast<const f32x4*>(nwg)[lane];
+        xv1 = reinterpret_cast<const f32x4*>(xg)[b1 * 64 + lane];
+        wv1 = reinterpret_cast<const f32x4*>(nwg)[b1 * 64 + lane];
       }
-      // 6-bit scales / mins of sub-blocks mq, mq+2, mq+4, mq+6 of row n (packing: dequant.rs:210-223)
-      const uint32_t s8 = (mq & 1) * 8;
-      const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
-      const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
-      const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
-      const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
-      const float scf[4] = {ub0(sc01), ub2(sc01), ub0(sc23), ub2(sc23)};
-      const float mnf[4] = {ub0(mn01), ub2(mn01), ub0(mn23), ub2(mn23)};
-      float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-      for (int pp = 0; pp < 4; pp++) {
-        i32x4 bw;
-        bw.x = (int)((r.q[pp].x >> sh) & 0x0F0F0F0Fu);
-        bw.y = (int)((r.q[pp].y >> sh) & 0x0F0F0F0Fu);
-        bw.z = (int)((r.q[pp].z >> sh) & 0x0F0F0F0Fu);
-        bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
-        const i32x4 zero = {0, 0, 0, 0};
-        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
-        // lanes mq<2: d = limb sums of sub-block 2pp+mq for row n.  V = D0*2^24 + D1*2^16 + D2*2^8 + D3; both halves
-        // are exact in f32 (|D0| <= 64*480, |D1..3| <= 128*480, so |(Da<<8)+Db| < 2^24)
-        const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
-        const float V = __builtin_fmaf(hi, 65536.0f, lo);
-        s1 = __builtin_fmaf(scf[pp], V, s1);
-        s2 = __builtin_fmaf(mnf[pp], xs4[pp], s2);
+    };
+    auto norm_block = [&](f32x4 v, f32x4 w, uint32_t b) {   // RMSNorm prologue: sum of squares of raw x, limbs of x * w
+      if (p0 == 0) {   // the norm belongs to the first input vector only
+        ss = __builtin_fmaf(v.x, v.x, ss);
+        ss = __builtin_fmaf(v.y, v.y, ss);
+        ss = __builtin_fmaf(v.z, v.z, ss);
+        ss = __builtin_fmaf(v.w, v.w, ss);
       }
-      const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
-      acc += (dd * sxb) * s1 - dmin * s2;
-      if (b + 1 == nblk_w) {   // last block of this (pass, tile): hand the partial sums to the epilogue
-        if (mq < 2) red[(size_t)(p * (2 * S_T) + ks * 2 + mq) * S_rpw + (rg * Rg + tl) * 16 + n] = acc;
-        acc = 0.0f;
+      stage_block(v * w, b, lane, limbs, xsum, sxs);
+    };
+    auto x_finish = [&](auto n_tiles) {
+      constexpr int NT = decltype(n_tiles)::value;
+      if (!nrm) {
+        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        LGH_WSTAMP(4);
+        for (uint32_t b = 0; b < nblk_w; b++) {
+          // the read precedes the limb stores into the same 1-KiB region (in-order LDS)
+          const f32x4 v = *reinterpret_cast<const f32x4*>(limbs + (size_t)b * 1024 + lane * 16);
+          stage_block(v, b, lane, limbs, xsum, sxs);
+        }
+      } else {
+        norm_block(xv0, wv0, 0);
+        if (nblk_w > 1) norm_block(xv1, wv1, 1);
+        for (uint32_t b = 2; b < nblk_w; b++)   // slices of more than two blocks (hidden sizes above 4096): behind the tiles
+          norm_block(reinterpret_cast<const f32x4*>(xg)[b * 64 + lane], reinterpret_cast<const f32x4*>(nwg)[b * 64 + lane], b);
       }
     };
 
-    uint32_t remaining = npp * ntile_w * nblk_w;
-#ifdef LGH_STAMPS
-    if (remaining > 2) {
-      bp = ip; btl = itl; bb = ib; issue(ip, itl, ib, Bq); advance();
-      consume(ap, atl, ab, A);
-      LGH_STAMP(2);
-      ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance();
-      consume(bp, btl, bb, Bq);
-      remaining -= 2;
-    }
-#endif
-    while (remaining > 2) {
-      bp = ip; btl = itl; bb = ib; issue(ip, itl, ib, Bq); advance();
-      consume(ap, atl, ab, A);
-      ap = ip; atl = itl; ab = ib; issue(ip, itl, ib, A); advance();
-      consume(bp, btl, bb, Bq);
-      remaining -= 2;
-    }
-    if (remaining == 2) {
-      bp = ip; btl = itl; bb = ib; issue(ip, itl, ib, Bq);
-      consume(ap, atl, ab, A);
-      consume(bp, btl, bb, Bq);
-    } else {   // remaining == 1
-      consume(ap, atl, ab, A);
+    RawT16 buf[kDepth];
+    Pos pos[kDepth];
+    // `run` for a static number of tiles put in flight up front; every path ends with nothing in flight
+    auto run = [&](auto n_first) {
+      constexpr int NF = decltype(n_first)::value;
+      LGH_WSTAMP(2);
+      x_request();
+#pragma unroll
+      for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+      LGH_WSTAMP(3);
+      x_finish(n_first);
+      LGH_WSTAMP(5);
+      if constexpr (NF < kDepth) {   // that was everything
+#pragma unroll
+        for (int j = 0; j < NF; j++) consume(pos[j], buf[j]);
+      } else {
+        uint32_t rem = nitems;       // not yet consumed; kDepth of them in flight
+        while (rem >= 2 * kDepth) {
+#pragma unroll
+          for (int j = 0; j < kDepth; j++) {
+            consume(pos[j], buf[j]);
+            pos[j] = nx; issue(nx, buf[j]); advance();
+          }
+          rem -= kDepth;
+        }
+        const uint32_t unissued = rem - kDepth;   // 0 .. kDepth-1
+#pragma unroll
+        for (int j = 0; j < kDepth; j++) {
+          consume(pos[j], buf[j]);
+          if ((uint32_t)j < unissued) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+        }
+#pragma unroll
+        for (int j = 0; j < kDepth - 1; j++)
+          if ((uint32_t)j < unissued) consume(pos[j], buf[j]);
+      }
+    };
+    if (nitems == 0) {
+      if (nblk_w == 0 && ntile_w > 0) {
+        // a k-slice beyond the last block (T does not divide the block count): its partial-sum slots must read as zero
+        for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; p++)
+          for (uint32_t tl = 0; tl < ntile_w; tl++)
+            if (mq < 2) red[(size_t)(p * (2 * S_T) + ks * 2 + mq) * S_rpw + (rg * Rg + tl) * 16 + n] = 0.0f;
+      } else if (nrm && p0 == 0 && nblk_w > 0 && rg == 0) {
+        // no tiles for this wave in this workgroup, but the norm still needs its slice's sum of squares
+        for (uint32_t b = 0; b < nblk_w; b++) {
+          const f32x4 v = reinterpret_cast<const f32x4*>(xg)[b * 64 + lane];
+          ss = __builtin_fmaf(v.x, v.x, ss);
+          ss = __builtin_fmaf(v.y, v.y, ss);
+          ss = __builtin_fmaf(v.z, v.z, ss);
+          ss = __builtin_fmaf(v.w, v.w, ss);
+        }
+      }
+    } else if (nitems == 1) {
+      run(std::integral_constant<int, 1>{});
+    } else if (nitems == 2) {
+      run(std::integral_constant<int, 2>{});
+    } else if (nitems == 3) {
+      run(std::integral_constant<int, 3>{});
+    } else {
+      run(std::integral_constant<int, kDepth>{});
     }
     p0 = p1;
     LGH_STAMP(3);
+    LGH_WSTAMP(6);
+  }
+  if (nrm) {   // row-group 0 covers every block of x exactly once
+    ss = wave_sum_to_lane63(ss);
+    if (lane == 63) ssq[wave] = rg == 0 ? ss : 0.0f;
   }
   __syncthreads();
   LGH_STAMP(4);
   mv_epilogue(L, S, wg, red, ssq, 2 * S.T);
   LGH_STAMP(5);
+  LGH_WSTAMP(7);
+  LGH_SPAN(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,11 +436,11 @@ __global__ void __launch_bounds__(MAXT) mvq_kernel(const MvLaunch L) {
 // ------------------------------------------------------------------------------------------------
 hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows) {
   if (k == 0 || k % 256 || n_rows == 0 || npass < 1 || npass > 4) return hipErrorInvalidValue;
-  const uint32_t nblk = k / 256, W = 16;
+  const uint32_t nblk = k / 256, W = kWaves;
   uint32_t T = 1;
   for (uint32_t t = 1; t <= W && t <= nblk; t++)
     if (nblk % t == 0) T = t;                       // largest divisor of nblk that fits the workgroup
-  if (T < 8 && nblk > W) T = W;                     // awkward block counts: uneven k-slices
+  if (T < W / 2 && nblk > W) T = W;                 // awkward block counts: uneven k-slices
   if (T > nblk) T = nblk;
   const uint32_t G = W / T >= 1 ? W / T : 1;
   const uint32_t nbw = (nblk + T - 1) / T;
@@ -393,32 +448,33 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   const uint32_t tiles_launch = (launch_rows + 15) / 16;
   uint32_t R = (tiles_launch + kNumCU - 1) / kNumCU;  // tiles per workgroup: one workgroup per CU
   R = (R + G - 1) / G * G;
+  const uint32_t threads = T * G * 64;
+  const uint32_t rmax = threads / 16 / G * G;         // the epilogue gives every row (pair) a thread
+  if (R > rmax) R = rmax;
   plan->units = nbw;
   plan->T = T;
   plan->G = G;
   plan->rows_per_wg = 16 * R;
   plan->n_wg = ((n_rows + 15) / 16 + R - 1) / R;
-  plan->threads = T * G * 64;
+  plan->threads = threads;
   plan->red_floats = (uint32_t)npass * 2 * T * 16 * R;
   return hipSuccess;
 }
 
-size_t mvq_lds_bytes(uint32_t k, uint32_t red_floats) {
-  const uint32_t nblk = k / 256;
-  return (size_t)k * 4 + (size_t)(k / 32) * 4 + (size_t)((nblk + 3) & ~3u) * 4 + (size_t)red_floats * 4 + 64;
+size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
+  return (((size_t)nwaves * nbw * (1024 + 32 + 4) + 15) & ~(size_t)15) + (size_t)red_floats * 4 + 64;
 }
 
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel<1024>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = mvq_lds_bytes(L.k, L.red_floats);
-  if (lds > 160 * 1024 || threads == 0 || threads > 1024 || n_wg == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((mvq_kernel<1024>), dim3(n_wg), dim3(threads), lds, st, L);
+  const size_t lds = mvq_lds_bytes(threads / 64, L.seg[0].units, L.red_floats);
+  if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(mvq_kernel, dim3(n_wg), dim3(threads), lds, st, L);
   return hipGetLastError();
 }
 

@@ -10,7 +10,7 @@
 using namespace lgh;
 
 #ifdef LGH_STAMPS
-namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); }
+namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); hipError_t mvq_spans(unsigned long long* host, int reset); }
 #include <algorithm>
 #include <cstdio>
 #endif
@@ -220,6 +220,9 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
     if ((rc = once())) return rc;
   hipEvent_t a, b;
   if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return LGH_OPERATION_FAILED;
+#ifdef LGH_STAMPS
+  (void)lgh::mvq_spans(nullptr, 1);
+#endif
   (void)hipEventRecord(a, t.c->stream);
   for (int i = 0; i < iters; i++)
     if ((rc = once())) break;
@@ -251,14 +254,30 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
         std::fprintf(stderr, "    %-16s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[i], v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
       }
       if (Ws[0].type == kDevQ4K_T16) {
-        std::vector<unsigned long long> ws(2048 * 16 * 2);
+        unsigned long long sp[128];
+        if (lgh::mvq_spans(sp, 0) == hipSuccess) {   // consecutive launches: busy span and idle gap between them
+          std::vector<double> busy, idle;
+          for (int i = 0; i < 64; i++) {
+            const int j = (i + 63) & 63;
+            if (sp[2 * i] == ~0ull || sp[2 * j] == ~0ull || sp[2 * i] < sp[2 * j]) continue;
+            busy.push_back((double)(sp[2 * i + 1] - sp[2 * i]) / 100.0);
+            idle.push_back((double)((long long)sp[2 * i] - (long long)sp[2 * j + 1]) / 100.0);
+          }
+          std::sort(busy.begin(), busy.end());
+          std::sort(idle.begin(), idle.end());
+          if (!busy.empty())
+            std::fprintf(stderr, "    launch spans (%zu): first start -> last end p50 %.2f us; previous last end -> first start p50 %.2f us (min %.2f)\n",
+                         busy.size(), busy[busy.size() / 2], idle[idle.size() / 2], idle[0]);
+        }
+        std::vector<unsigned long long> ws(2048 * 16 * 8);
         if (lgh::mvq_read_wave_stamps(ws.data(), ws.size()) == hipSuccess) {
           const size_t nw = plan.threads / 64, ng = std::min<size_t>(nwg, 2048);
-          for (int i = 0; i < 2; i++) {
-            std::fprintf(stderr, "    per-wave %-8s p50:", i == 0 ? "start" : "staged");
+          const char* wn[8] = {"start", "scalars", "pre-x", "issued", "x here", "staged", "streamed", "end"};
+          for (int i = 0; i < 8; i++) {
+            std::fprintf(stderr, "    per-wave %-8s p50:", wn[i]);
             for (size_t w = 0; w < nw; w++) {
               std::vector<double> v;
-              for (size_t g = 0; g < ng; g++) v.push_back((double)(ws[(g * 16 + w) * 2 + i] - t0) / 100.0);
+              for (size_t g = 0; g < ng; g++) v.push_back((double)(ws[(g * 16 + w) * 8 + i] - t0) / 100.0);
               std::sort(v.begin(), v.end());
               std::fprintf(stderr, " %5.2f", v[v.size() / 2]);
             }
