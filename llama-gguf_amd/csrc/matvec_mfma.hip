@@ -169,47 +169,49 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 // flight right behind it, converts x to limbs in its private LDS region while the tiles travel, and streams.  Few,
 // fat waves on purpose: the dispatcher starts the waves of a grid over ~1 us (measured: the 16 waves of a 1024-thread
 // workgroup began 0.25 / 0.33 / 0.67 / 1.05 us after launch, 4 at a time), which a barrier turns into idle time.
-__global__ void __launch_bounds__(kWaves * 64) mvq_kernel(const MvLaunch L) {
+// A wave issues at most one instruction every ~4 cycles, so a latency-bound prologue costs 1.7 ns PER INSTRUCTION
+// (measured: the first, general version spent 590 instructions = 1.0 us before its first vector load).  Hence:
+//   * everything launch-uniform is computed on the host, packed into eight scalars and delivered by KERNARG PRELOAD
+//     (SGPRs filled at wave launch, no load: -mllvm -amdgpu-kernarg-preload-count=8);
+//   * per-segment fields come from `L` in one batch of scalar loads, per-pass fields only for passes that exist.
+// geom  = T | G << 8 | nbw << 16 | do_norm << 31         geom2 = nblk | Rg << 16        wbpack = wg_begin[1] | wg_begin[2] << 16
+// offA/B/C = byte strides of a workgroup / a row-group / a k-slice inside one pass's tile array
+__global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
+                                                          uint32_t offA, uint32_t offB, uint32_t offC, uint32_t lds_red_off,
+                                                          const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  // Kernel arguments are read in TWO dependent rounds of scalar loads, each issued as one batch (a lazily loaded field
-  // costs its own ~0.2-0.4 us round trip, and there were five of them in a row before the first vector load):
-  // round 1 picks the segment, round 2 fetches everything the wave needs from it, for all four passes unconditionally.
   const uint32_t bid = blockIdx.x;
-  const int nseg = L.nseg;
-  const uint32_t wb1 = L.seg[1].wg_begin, wb2 = L.seg[2].wg_begin;
-  const int s = (int)(nseg > 1 && bid >= wb1) + (int)(nseg > 2 && bid >= wb2);
+  const int s = (int)(bid >= (wbpack & 0xFFFFu)) + (int)(bid >= (wbpack >> 16));   // 0xFFFF = no such segment
   const MvSeg& S = L.seg[s];
-  const uint32_t S_T = S.T, S_G = S.G, S_units = S.units, S_nblk = S.nblk, S_rpw = S.rows_per_wg, S_nrows = S.n_rows;
+  const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin;
   const int S_npass = S.npass;
-  const uint32_t wg = bid - S.wg_begin;
-  const uint8_t* P_plane[4] = {S.pass[0].plane[0], S.pass[1].plane[0], S.pass[2].plane[0], S.pass[3].plane[0]};
-  const float* P_x[4] = {S.pass[0].x, S.pass[1].x, S.pass[2].x, S.pass[3].x};
-  const int* P_sel[4] = {S.pass[0].sel, S.pass[1].sel, S.pass[2].sel, S.pass[3].sel};
-  const uint64_t P_stride[4] = {S.pass[0].sel_stride[0], S.pass[1].sel_stride[0], S.pass[2].sel_stride[0], S.pass[3].sel_stride[0]};
-  const float* L_norm_w = L.norm_w;
-  const uint32_t L_red_floats = L.red_floats;
+  const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x7FFFu;
+  const bool nrm = (geom >> 31) != 0;
+  const uint32_t S_nblk = geom2 & 0xFFFFu, Rg = geom2 >> 16;
+  const uint32_t S_rpw = 16u * Rg * S_G;
+  const uint32_t wg = bid - S_wgb;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
-  const bool nrm = L.do_norm != 0;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   LGH_WSTAMP(0);
   LGH_SPAN(0);
-  const bool active = wave < S_T * S_G;
-  const uint32_t ks = active ? wave % S_T : 0, rg = active ? wave / S_T : 0;
-  const uint32_t nbw = S_units;                                   // blocks per k-slice
+  uint32_t ks = wave, rg = 0;                                     // wave = rg * T + ks (at most G - 1 subtractions)
+  while (ks >= S_T) { ks -= S_T; rg++; }
+  const bool active = rg < S_G;
   const uint32_t blk0 = ks * nbw;
-  const uint32_t nblk_w = active && blk0 < S_nblk ? min(nbw, S_nblk - blk0) : 0;
-  const uint32_t R = S_rpw >> 4, Rg = R / S_G;                    // tiles per workgroup / per row-group
+  uint32_t nblk_w = active && blk0 < S_nblk ? min(nbw, S_nblk - blk0) : 0;   // (not const: see the phase loop)
   const uint32_t ntiles = (S_nrows + 15) >> 4;
-  const uint32_t tile0 = wg * R + rg * Rg;
-  const uint32_t ntile_w = active && tile0 < ntiles ? min(Rg, ntiles - tile0) : 0;
-  // LDS: per-wave private limbs / sub-block sums / scales, then the partial-sum slots and the per-wave sum(x^2)
+  const uint32_t tile0 = (wg * S_G + rg) * Rg;
+  uint32_t ntile_w = active && tile0 < ntiles ? min(Rg, ntiles - tile0) : 0;
+  // LDS: per-wave private limbs / sub-block sums / scales (1060 B per block), then the partial-sum slots and the
+  // per-wave sum(x^2)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
-  int8_t* limbs = reinterpret_cast<int8_t*>(smem8) + (size_t)wave * nbw * 1024;
-  const uint32_t limbs_lds = lds_base + wave * nbw * 1024;
-  float* xsum = reinterpret_cast<float*>(smem8 + (size_t)nwaves * nbw * 1024) + (size_t)wave * nbw * 8;
-  float* sxs = reinterpret_cast<float*>(smem8 + (size_t)nwaves * nbw * (1024 + 32)) + (size_t)wave * nbw;
-  float* red = reinterpret_cast<float*>(smem8 + (((size_t)nwaves * nbw * (1024 + 32 + 4) + 15) & ~(size_t)15));
+  const uint32_t wreg = wave * nbw * 1060u;
+  int8_t* limbs = reinterpret_cast<int8_t*>(smem8 + wreg);
+  const uint32_t limbs_lds = lds_base + wreg;
+  float* xsum = reinterpret_cast<float*>(smem8 + wreg + nbw * 1024u);
+  float* sxs = reinterpret_cast<float*>(smem8 + wreg + nbw * 1056u);
+  float* red = reinterpret_cast<float*>(smem8 + lds_red_off);
   float* ssq = red + L_red_floats;
   // lane roles inside an MFMA
   const uint32_t n = lane & 15, c = lane >> 4;                    // B: weight row n, k-chunk c; D: row n, limb quad mq = c
@@ -220,15 +222,27 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(const MvLaunch L) {
   const uint32_t a_off = ((c >> 1) * 4 + (n & 3)) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
   const uint32_t mq = c;                                          // D lanes with mq < 2 hold sub-block 2p + mq
 
-  // per-pass base of this wave's tiles, resolved once (scalar): the MoE expert index is a SCALAR load — a vector load
-  // would sit in the same in-order queue as the weight tiles
+  // per-pass base of this wave's tiles and input vector.  The MoE expert index is a SCALAR load — a vector load would
+  // sit in the same in-order queue as the weight tiles.
+  const uint64_t woff = (uint64_t)wg * offA + (uint64_t)(rg * offB + ks * offC);
   const uint8_t* pb[4] = {nullptr, nullptr, nullptr, nullptr};
+  const float* P_x[4] = {nullptr, nullptr, nullptr, nullptr};
 #pragma unroll
   for (int p = 0; p < 4; p++) {
-    uint32_t e32 = 0;
-    if (P_sel[p]) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(P_sel[p]) : "memory");
-    pb[p] = P_plane[p] + (uint64_t)e32 * P_stride[p] + ((size_t)tile0 * S_nblk + blk0) * kTileBytes;
+    if (p < S_npass) {
+      const MvPass& P = S.pass[p];
+      const uint8_t* plane = P.plane[0];
+      const int* sel = P.sel;
+      P_x[p] = P.x;
+      if (sel) {
+        uint32_t e32;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(sel) : "memory");
+        plane += (uint64_t)e32 * P.sel_stride[0];
+      }
+      pb[p] = plane + woff;
+    }
   }
+  const float* L_norm_w = nrm ? L.norm_w : nullptr;
   LGH_WSTAMP(1);
   struct Pos { uint32_t p, tl, b; };
   auto issue = [&](const Pos& q, RawT16& r) {
@@ -300,6 +314,9 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(const MvLaunch L) {
     const float* xg = x_of(p0) + (size_t)blk0 * 256;   // this wave's k-slice
     const float* nwg = L_norm_w + (size_t)blk0 * 256;
     nx.p = (uint32_t)p0; nx.tl = 0; nx.b = 0;
+    // Opaque to the optimizer (the values do not change): otherwise every shape's loop-invariant bookkeeping — ~300
+    // scalar instructions, most of them for paths not taken — is hoisted in front of the first load, at 1.7 ns each.
+    asm volatile("" : "+s"(nblk_w), "+s"(ntile_w));
     const uint32_t nitems = npp * ntile_w * nblk_w;
 
     // ---- x staging.  x_request goes out FIRST, the caller's tile issues right behind it; loads return in order, so
@@ -425,7 +442,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(const MvLaunch L) {
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue(L, S, wg, red, ssq, 2 * S.T);
+  mv_epilogue(L, S, wg, red, ssq, 2 * S_T);
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);
@@ -461,8 +478,9 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   return hipSuccess;
 }
 
+static uint32_t mvq_red_offset(uint32_t nwaves, uint32_t nbw) { return (nwaves * nbw * 1060u + 15u) & ~15u; }
 size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
-  return (((size_t)nwaves * nbw * (1024 + 32 + 4) + 15) & ~(size_t)15) + (size_t)red_floats * 4 + 64;
+  return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
@@ -474,7 +492,21 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
   }
   const size_t lds = mvq_lds_bytes(threads / 64, L.seg[0].units, L.red_floats);
   if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(mvq_kernel, dim3(n_wg), dim3(threads), lds, st, L);
+  const MvSeg& S0 = L.seg[0];
+  for (int i = 1; i < L.nseg; i++)   // the launch-uniform geometry travels as preloaded scalars
+    if (L.seg[i].T != S0.T || L.seg[i].G != S0.G || L.seg[i].units != S0.units || L.seg[i].nblk != S0.nblk ||
+        L.seg[i].rows_per_wg != S0.rows_per_wg || L.seg[i].wg_begin >= 0xFFFFu)
+      return hipErrorInvalidValue;
+  const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
+  if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return hipErrorInvalidValue;
+  const uint64_t offA64 = (uint64_t)(S0.rows_per_wg / 16) * S0.nblk * kTileBytes;
+  if (offA64 > 0xFFFFFFFFull) return hipErrorInvalidValue;
+  const uint32_t wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
+  const uint32_t geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
+  const uint32_t geom2 = S0.nblk | Rg << 16;
+  const uint32_t offA = (uint32_t)offA64, offB = Rg * S0.nblk * kTileBytes, offC = S0.units * kTileBytes;
+  hipLaunchKernelGGL(mvq_kernel, dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, offA, offB, offC,
+                     mvq_red_offset(threads / 64, S0.units), L);
   return hipGetLastError();
 }
 
