@@ -42,6 +42,8 @@ __host__ __device__ inline uint32_t blk_bytes(int t) {
 }
 
 constexpr int kDevQ4K_T16 = 1012;  // device-only type tag: Q4_K in the 16-row tile layout of matvec_mfma.hip
+constexpr int kDevQ6K_T16 = 1014;  // Q6_K in its 16-row tile layout (3392 B per tile), same kernel
+inline bool mfma_type(int t) { return t == kDevQ4K_T16 || t == kDevQ6K_T16; }
 
 // ---------------------------------------------------------------------------------------------
 // Device weight layouts (what lgh_upload_tensor leaves in HBM).  Byte counts equal the GGUF payload;
@@ -147,7 +149,8 @@ int mv_symbol(const MvLaunch& L);
 // int8-MFMA path (matvec_mfma.hip): Q4_K in the tile16 layout
 hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
-hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
+hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
+hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
 hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
                              float eps, const float* resid, hipStream_t st);
 

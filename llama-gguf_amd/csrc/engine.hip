@@ -75,7 +75,7 @@ LayoutInfo layout_for(int src_type) {
 }
 
 bool fused_type(int t) {
-  return t == kDevQ4K_T16 || t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
+  return t == kDevQ4K_T16 || t == kDevQ6K_T16 || t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
 }
 
 // Upload one matrix (or expert `slot` of a stack, or the whole stack when slot < 0) given in native
@@ -90,9 +90,15 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
   const uint32_t n_in_payload = slot < 0 ? n_stack : 1;
   if (nbytes != per_expert_src * n_in_payload) return fail(c, LGH_SHAPE_MISMATCH, "tensor byte size does not match its shape");
   uint64_t blocks_per_expert = (uint64_t)n * (k / li.belems);
-  const bool t16 = src_type == LGH_TYPE_Q4_K;   // int8-MFMA tile layout: rows padded to 16
+  const bool t16 = src_type == LGH_TYPE_Q4_K || src_type == LGH_TYPE_Q6_K;   // int8-MFMA tile layouts: rows padded to 16
   if (t16) {
-    li.dev_type = kDevQ4K_T16;
+    if (src_type == LGH_TYPE_Q4_K) {
+      li.dev_type = kDevQ4K_T16;                       // 2304 B per 16 rows x 256 elements
+    } else {
+      li.dev_type = kDevQ6K_T16;                       // 3392 B per tile: 212 B per row-block, one plane
+      li.nplanes = 1;
+      li.bpb[0] = 212; li.bpb[1] = li.bpb[2] = li.bpb[3] = 0;
+    }
     blocks_per_expert = (uint64_t)((n + 15) / 16) * 16 * (k / 256);
   }
   if (!W.present()) {
@@ -131,7 +137,9 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
     if (li.dev_type == LGH_TYPE_F32) {
       e = dequant_launch(src_type, src, (float*)(W.plane[0] + (uint64_t)(e0 + i) * W.stack_stride[0]), (uint64_t)n * k, c->stream);
     } else if (t16) {
-      e = repack_q4k_t16_launch(src, W.base + (uint64_t)(e0 + i) * W.stack_stride[0], n, k / 256, c->stream);
+      uint8_t* dstp = W.base + (uint64_t)(e0 + i) * W.stack_stride[0];
+      e = src_type == LGH_TYPE_Q4_K ? repack_q4k_t16_launch(src, dstp, n, k / 256, c->stream)
+                                    : repack_q6k_t16_launch(src, dstp, n, k / 256, c->stream);
     } else {
       uint64_t po[4];
       for (int p = 0; p < 4; p++) po[p] = (uint64_t)(W.plane[p] - W.base) + (uint64_t)(e0 + i) * W.stack_stride[p];
@@ -260,7 +268,7 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
   SegSpec a[3], b[3];
   int na = 0, nb = 0;
   for (int s = 0; s < nseg; s++) {
-    if (specs[s].W[0]->type == kDevQ4K_T16) a[na++] = specs[s];
+    if (mfma_type(specs[s].W[0]->type)) a[na++] = specs[s];
     else b[nb++] = specs[s];
   }
   int rc = LGH_OK;

@@ -72,7 +72,8 @@ hipError_t mvq_spans(unsigned long long* host, int reset) {
 #define LGH_SPAN(i)
 #endif
 
-constexpr int kTileBytes = 2304;
+constexpr int kTileBytes = 2304;      // Q4_K tile16
+constexpr int kTileBytesQ6 = 3392;    // Q6_K tile16
 
 // ------------------------------------------------------------------------------------------------
 // native [row][block] Q4_K  ->  tile16
@@ -107,6 +108,74 @@ hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_ro
 }
 
 // ------------------------------------------------------------------------------------------------
+// native [row][block] Q6_K  ->  tile16 (3392 B per 16 rows x 256 elements)
+//
+// The 6-bit weights q' = ql | qh << 4 (0..63; the reference subtracts 32, dequant.rs:338-341) of MFMA step pp
+// (elements 64pp .. 64pp+63) and k-chunk c (16 elements) of row n belong to lane 16c + n.  Per lane and step:
+//   N0, N1   byte t = w[t] | w[t+4] << 4          (w = low nibbles of elements 0-7 / 8-15 of the chunk)
+//   H        byte t = f[t] | f[t+4] << 2 | f[t+8] << 4 | f[t+12] << 6   (f = the 2 high bits)
+// so B-operand dword j (elements 4j..4j+3) = nibbles_j | ((H >> 2j) & 0x03030303) << 4 with plain 32-bit ops.
+//   [0    , 1024)  lane-major 16 B: N0,N1 of steps 0 and 1        [1024, 2048)  N0,N1 of steps 2 and 3
+//   [2048 , 3072)  lane-major 16 B: H of steps 0..3
+//   [3072 , 3328)  row-major 16 B: the 16 int8 sub-block scales    [3328 , 3360)  the 16 rows' f16 d   (+32 B pad)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t q6_raw(const uint8_t* b, uint32_t i) {   // q' of element i of a native block
+  const uint32_t hn = i >> 7, r = i & 127, t = r >> 5, l = r & 31;
+  const uint32_t lb = b[hn * 64 + l + 32 * (t & 1)];
+  const uint32_t lo = t < 2 ? (lb & 0x0Fu) : (lb >> 4);
+  return lo | (((b[128 + hn * 32 + l] >> (2 * t)) & 3u) << 4);
+}
+
+__global__ void __launch_bounds__(256) repack_q6k_t16_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ dst,
+                                                            uint32_t n_rows, uint32_t nblk, uint64_t total) {
+  // one thread per (row, block, step pp): idx = ((row * nblk) + b) * 4 + pp
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+    const uint32_t pp = (uint32_t)(idx & 3);
+    const uint64_t rb = idx >> 2;
+    const uint32_t row = (uint32_t)(rb / nblk), b = (uint32_t)(rb % nblk);
+    const uint32_t rt = row >> 4, n = row & 15;
+    uint8_t* tile = dst + ((size_t)rt * nblk + b) * kTileBytesQ6;
+    const bool live = row < n_rows;
+    const uint8_t* src = raw + ((size_t)row * nblk + b) * 210;
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+      uint32_t w[16];
+#pragma unroll
+      for (uint32_t t = 0; t < 16; t++) w[t] = live ? q6_raw(src, 64 * pp + 16 * c + t) : 0u;
+      uint32_t N0 = 0, N1 = 0, H = 0;
+#pragma unroll
+      for (uint32_t t = 0; t < 4; t++) {
+        N0 |= ((w[t] & 15u) | (w[t + 4] & 15u) << 4) << (8 * t);
+        N1 |= ((w[t + 8] & 15u) | (w[t + 12] & 15u) << 4) << (8 * t);
+        H |= ((w[t] >> 4) | (w[t + 4] >> 4) << 2 | (w[t + 8] >> 4) << 4 | (w[t + 12] >> 4) << 6) << (8 * t);
+      }
+      const uint32_t lane = 16 * c + n;
+      uint32_t* nib = reinterpret_cast<uint32_t*>(tile + (pp >> 1) * 1024 + lane * 16 + (pp & 1) * 8);
+      nib[0] = N0;
+      nib[1] = N1;
+      *reinterpret_cast<uint32_t*>(tile + 2048 + lane * 16 + pp * 4) = H;
+    }
+    // scales 4pp .. 4pp+3 of the row; d once per (row, block)
+    uint32_t sc = 0;
+    if (live) sc = (uint32_t)src[192 + 4 * pp] | (uint32_t)src[193 + 4 * pp] << 8 | (uint32_t)src[194 + 4 * pp] << 16 | (uint32_t)src[195 + 4 * pp] << 24;
+    *reinterpret_cast<uint32_t*>(tile + 3072 + n * 16 + pp * 4) = sc;
+    if (pp == 0) *reinterpret_cast<uint16_t*>(tile + 3328 + n * 2) = live ? (uint16_t)(src[208] | src[209] << 8) : (uint16_t)0;
+    if (pp == 1 && n == 0) {   // the pad, so that repacked buffers are fully defined
+#pragma unroll
+      for (int i = 0; i < 8; i++) *reinterpret_cast<uint32_t*>(tile + 3360 + 4 * i) = 0u;
+    }
+  }
+}
+
+hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st) {
+  const uint64_t total = (uint64_t)((n_rows + 15) / 16) * 16 * nblk * 4;
+  uint64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(repack_q6k_t16_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, raw, dst, n_rows, nblk, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // kernel
 // ------------------------------------------------------------------------------------------------
 struct RawT16 { u32x4 hd; u32x4 q[4]; };
@@ -125,7 +194,7 @@ __device__ __forceinline__ float wave_max_all(float v) {  // max over the 64 lan
 
 // One 256-element block of x -> limbs / sub-block sums / scale in LDS.  Called by a whole wave: lane i owns
 // elements 4i..4i+3 of the block.
-__device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane, int8_t* limbs, float* xsum, float* sxs) {
+__device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane, int8_t* limbs, float* xsum, float* xs16, float* sxs) {
   const float amax = wave_max_all(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
   uint32_t e = (__float_as_uint(amax) >> 23) & 0xFFu;       // biased exponent: amax in [2^(e-127), 2^(e-126))
   e = e < 30u ? 30u : (e > 250u ? 250u : e);                 // vanishing / overflowing blocks: clamp (|x'| stays < 1)
@@ -153,7 +222,8 @@ __device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane
   for (int i = 0; i < 4; i++) *reinterpret_cast<uint32_t*>(limbs + ((size_t)(blk * 8 + g) * 4 + i) * 32 + kin) = limb[i];
   float gs = (v.x + v.y) + (v.z + v.w);                      // f32 sum of the sub-block's x (reference: x_acc, simd.rs:1002-1008)
   gs += dpp_f<0xB1>(gs);
-  gs += dpp_f<0x4E>(gs);
+  gs += dpp_f<0x4E>(gs);                                     // the 4 lanes of a 16-element chunk (Q6_K's scale granularity)
+  if ((lane & 3) == 0) xs16[blk * 16 + ((lane >> 2) & 3) * 4 + (lane >> 4)] = gs;   // chunk j = lane/4 at [j & 3][j >> 2]
   gs += dpp_f<0x141>(gs);                                    // row_half_mirror: the 8 lanes of a sub-block
   if ((lane & 7) == 0) xsum[(blk * 2 + (g & 1)) * 4 + (g >> 1)] = gs;   // layout [blk][mq = g&1][p = g>>1]
   if (lane == 0) sxs[blk] = __uint_as_float((e + 1u - 30u) << 23);      // s * 2^-30,  s = 2^(e-126)
@@ -176,15 +246,18 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 //   * per-segment fields come from `L` in one batch of scalar loads, per-pass fields only for passes that exist.
 // geom  = T | G << 8 | nbw << 16 | do_norm << 31         geom2 = nblk | Rg << 16        wbpack = wg_begin[1] | wg_begin[2] << 16
 // offA/B/C = byte strides of a workgroup / a row-group / a k-slice inside one pass's tile array
+// FMT: 0 = every segment Q4_K, 1 = every segment Q6_K, 2 = mixed (the segment's type decides at run time)
+template <int FMT>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
-                                                          uint32_t offA, uint32_t offB, uint32_t offC, uint32_t lds_red_off,
-                                                          const MvLaunch L) {
+                                                          uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   const uint32_t bid = blockIdx.x;
   const int s = (int)(bid >= (wbpack & 0xFFFFu)) + (int)(bid >= (wbpack >> 16));   // 0xFFFF = no such segment
   const MvSeg& S = L.seg[s];
   const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin;
   const int S_npass = S.npass;
+  const bool is_q6 = FMT == 1 || (FMT == 2 && S.type == kDevQ6K_T16);
+  const uint32_t tb = is_q6 ? (uint32_t)kTileBytesQ6 : (uint32_t)kTileBytes;
   const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x7FFFu;
   const bool nrm = (geom >> 31) != 0;
   const uint32_t S_nblk = geom2 & 0xFFFFu, Rg = geom2 >> 16;
@@ -203,14 +276,15 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const uint32_t ntiles = (S_nrows + 15) >> 4;
   const uint32_t tile0 = (wg * S_G + rg) * Rg;
   uint32_t ntile_w = active && tile0 < ntiles ? min(Rg, ntiles - tile0) : 0;
-  // LDS: per-wave private limbs / sub-block sums / scales (1060 B per block), then the partial-sum slots and the
-  // per-wave sum(x^2)
+  // LDS: per-wave private region, 1136 B per block of its k-slice: limbs 1024 | 32-element sums 32 | 16-element sums 64 |
+  // scale 4 (+12 pad); then the partial-sum slots and the per-wave sum(x^2)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
-  const uint32_t wreg = wave * nbw * 1060u;
+  const uint32_t wreg = wave * nbw * 1136u;
   int8_t* limbs = reinterpret_cast<int8_t*>(smem8 + wreg);
   const uint32_t limbs_lds = lds_base + wreg;
   float* xsum = reinterpret_cast<float*>(smem8 + wreg + nbw * 1024u);
-  float* sxs = reinterpret_cast<float*>(smem8 + wreg + nbw * 1056u);
+  float* xs16 = reinterpret_cast<float*>(smem8 + wreg + nbw * 1056u);
+  float* sxs = reinterpret_cast<float*>(smem8 + wreg + nbw * 1120u);
   float* red = reinterpret_cast<float*>(smem8 + lds_red_off);
   float* ssq = red + L_red_floats;
   // lane roles inside an MFMA
@@ -221,10 +295,14 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const bool a_valid = n < 8 && (n >> 2) == (c >> 1);
   const uint32_t a_off = ((c >> 1) * 4 + (n & 3)) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
   const uint32_t mq = c;                                          // D lanes with mq < 2 hold sub-block 2p + mq
+  // Q6_K scales every 16 elements, so its A operand is block-diagonal over the FOUR k-chunks: rows 4c'..4c'+3 = the limbs
+  // of chunk c', and lane group mq = c of D holds the limb sums of chunk c of row n
+  const bool a_valid6 = (n >> 2) == c;
+  const uint32_t a_off6 = (c >> 1) * 128 + (n & 3) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
 
   // per-pass base of this wave's tiles and input vector.  The MoE expert index is a SCALAR load — a vector load would
   // sit in the same in-order queue as the weight tiles.
-  const uint64_t woff = (uint64_t)wg * offA + (uint64_t)(rg * offB + ks * offC);
+  const uint64_t woff = ((uint64_t)tile0 * S_nblk + blk0) * tb;
   const uint8_t* pb[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* P_x[4] = {nullptr, nullptr, nullptr, nullptr};
 #pragma unroll
@@ -245,12 +323,19 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const float* L_norm_w = nrm ? L.norm_w : nullptr;
   LGH_WSTAMP(1);
   struct Pos { uint32_t p, tl, b; };
-  auto issue = [&](const Pos& q, RawT16& r) {
+  auto issue = [&](const Pos& q, RawT16& r) {   // five loads per tile in either format (the vmcnt bookkeeping counts on it)
     const uint8_t* base = q.p == 0 ? pb[0] : q.p == 1 ? pb[1] : q.p == 2 ? pb[2] : pb[3];
-    const uint8_t* tile = base + ((size_t)q.tl * S_nblk + q.b) * kTileBytes;
-    r.hd = ldg_nt128(tile + lane_off_hd);
+    const uint8_t* tile = base + ((size_t)q.tl * S_nblk + q.b) * tb;
+    if (is_q6) {
+      r.hd = ldg_nt128(tile + 3072 + n * 16);
 #pragma unroll
-    for (int pp = 0; pp < 4; pp++) r.q[pp] = ldg_nt128(tile + pp * 512 + lane_off_q);
+      for (int i = 0; i < 3; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
+      r.q[3].x = ldg_nt32(tile + 3328 + (n >> 1) * 4);
+    } else {
+      r.hd = ldg_nt128(tile + lane_off_hd);
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) r.q[pp] = ldg_nt128(tile + pp * 512 + lane_off_q);
+    }
   };
 
   LGH_STAMP(0);
@@ -262,7 +347,13 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   float ss = 0.0f;   // sum of squares of this wave's slice of x (RMSNorm prologue; row-group 0 covers all of x)
   float acc = 0.0f;
 
-  auto consume = [&](const Pos& q, const RawT16& r) {
+  auto finish_tile = [&](const Pos& q) {   // last block of a (pass, tile): lane groups -> one partial sum per row
+    float t = acc + __shfl_xor(acc, 16, 64);
+    if (is_q6) t += __shfl_xor(t, 32, 64);   // Q4_K: groups 0,1 carry the row; Q6_K: all four
+    if (mq == 0) red[(size_t)(q.p * S_T + ks) * S_rpw + (rg * Rg + q.tl) * 16 + n] = t;
+    acc = 0.0f;
+  };
+  auto consume4 = [&](const Pos& q, const RawT16& r) {
     // this block's x limbs, sub-block sums and scale: written by this same wave (LDS ops of a wave execute in order)
     i32x4 areg[4];
 #pragma unroll
@@ -300,10 +391,47 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     }
     const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
     acc += (dd * sxb) * s1 - dmin * s2;
-    if (q.b + 1 == nblk_w) {   // last block of this (pass, tile): hand the partial sums to the epilogue
-      if (mq < 2) red[(size_t)(q.p * (2 * S_T) + ks * 2 + mq) * S_rpw + (rg * Rg + q.tl) * 16 + n] = acc;
-      acc = 0.0f;
+    if (q.b + 1 == nblk_w) finish_tile(q);
+  };
+
+  auto consume6 = [&](const Pos& q, const RawT16& r) {
+    i32x4 areg[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      i32x4 t = {0, 0, 0, 0};
+      if (a_valid6) t = *reinterpret_cast<const i32x4*>(limbs + (size_t)(q.b * 8 + 2 * pp) * 128 + a_off6);
+      areg[pp] = t;
     }
+    const f32x4 xs = *reinterpret_cast<const f32x4*>(xs16 + q.b * 16 + c * 4);   // sums of x over chunk 4pp + c
+    const float sxb = sxs[q.b];
+    const uint32_t s8 = c * 8;
+    const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};   // int8 scales 4pp .. 4pp+3 of row n (dequant.rs:343-350)
+    float s1 = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+      const uint32_t H = pp == 0 ? r.q[2].x : pp == 1 ? r.q[2].y : pp == 2 ? r.q[2].z : r.q[2].w;
+      i32x4 bw;   // q' = ql | qh << 4, 0..63; the reference's "- 32" is applied through the chunk's sum of x below
+      bw.x = (int)((N0 & 0x0F0F0F0Fu) | ((H & 0x03030303u) << 4));
+      bw.y = (int)(((N0 >> 4) & 0x0F0F0F0Fu) | (((H >> 2) & 0x03030303u) << 4));
+      bw.z = (int)((N1 & 0x0F0F0F0Fu) | (((H >> 4) & 0x03030303u) << 4));
+      bw.w = (int)(((N1 >> 4) & 0x0F0F0F0Fu) | (((H >> 6) & 0x03030303u) << 4));
+      const i32x4 zero = {0, 0, 0, 0};
+      const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
+      // lane group mq: d = limb sums of chunk 4pp + mq for row n  (|D0| <= 64*63*16, so the high half is exact in f32;
+      // the low half may round at 2^-24 of a term that is itself 2^-16 of the sum)
+      const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+      const float V = __builtin_fmaf(hi, 65536.0f, lo);
+      const float scf = (float)(int)__builtin_amdgcn_sbfe((int)hdw[pp], s8, 8);
+      s1 = __builtin_fmaf(scf, __builtin_fmaf(sxb, V, -32.0f * xs[pp]), s1);
+    }
+    const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
+    acc = __builtin_fmaf(h2f(dh), s1, acc);
+    if (q.b + 1 == nblk_w) finish_tile(q);
+  };
+  auto consume = [&](const Pos& q, const RawT16& r) {
+    if (is_q6) consume6(q, r);
+    else consume4(q, r);
   };
 
   auto x_of = [&](int p) { return p == 0 ? P_x[0] : p == 1 ? P_x[1] : p == 2 ? P_x[2] : P_x[3]; };
@@ -348,7 +476,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         ss = __builtin_fmaf(v.z, v.z, ss);
         ss = __builtin_fmaf(v.w, v.w, ss);
       }
-      stage_block(v * w, b, lane, limbs, xsum, sxs);
+      stage_block(v * w, b, lane, limbs, xsum, xs16, sxs);
     };
     auto x_finish = [&](auto n_tiles) {
       constexpr int NT = decltype(n_tiles)::value;
@@ -361,7 +489,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         for (uint32_t b = 0; b < nblk_w; b++) {
           // the read precedes the limb stores into the same 1-KiB region (in-order LDS)
           const f32x4 v = *reinterpret_cast<const f32x4*>(limbs + (size_t)b * 1024 + lane * 16);
-          stage_block(v, b, lane, limbs, xsum, sxs);
+          stage_block(v, b, lane, limbs, xsum, xs16, sxs);
         }
       } else {
         norm_block(xv0, wv0, 0);
@@ -412,7 +540,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         // a k-slice beyond the last block (T does not divide the block count): its partial-sum slots must read as zero
         for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; p++)
           for (uint32_t tl = 0; tl < ntile_w; tl++)
-            if (mq < 2) red[(size_t)(p * (2 * S_T) + ks * 2 + mq) * S_rpw + (rg * Rg + tl) * 16 + n] = 0.0f;
+            if (mq == 0) red[(size_t)(p * S_T + ks) * S_rpw + (rg * Rg + tl) * 16 + n] = 0.0f;
       } else if (nrm && p0 == 0 && nblk_w > 0 && rg == 0) {
         // no tiles for this wave in this workgroup, but the norm still needs its slice's sum of squares
         for (uint32_t b = 0; b < nblk_w; b++) {
@@ -442,7 +570,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue(L, S, wg, red, ssq, 2 * S_T);
+  mv_epilogue(L, S, wg, red, ssq, S_T);
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);
@@ -474,40 +602,51 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   plan->rows_per_wg = 16 * R;
   plan->n_wg = ((n_rows + 15) / 16 + R - 1) / R;
   plan->threads = threads;
-  plan->red_floats = (uint32_t)npass * 2 * T * 16 * R;
+  plan->red_floats = (uint32_t)npass * T * 16 * R;
   return hipSuccess;
 }
 
-static uint32_t mvq_red_offset(uint32_t nwaves, uint32_t nbw) { return (nwaves * nbw * 1060u + 15u) & ~15u; }
+static uint32_t mvq_red_offset(uint32_t nwaves, uint32_t nbw) { return nwaves * nbw * 1136u; }
 size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
-hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+template <int FMT>
+static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
+                         uint32_t geom2, uint32_t red_off) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const size_t lds = mvq_lds_bytes(threads / 64, L.seg[0].units, L.red_floats);
-  if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((mvq_kernel<FMT>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
+  return hipGetLastError();
+}
+
+hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
   const MvSeg& S0 = L.seg[0];
-  for (int i = 1; i < L.nseg; i++)   // the launch-uniform geometry travels as preloaded scalars
-    if (L.seg[i].T != S0.T || L.seg[i].G != S0.G || L.seg[i].units != S0.units || L.seg[i].nblk != S0.nblk ||
-        L.seg[i].rows_per_wg != S0.rows_per_wg || L.seg[i].wg_begin >= 0xFFFFu)
+  const size_t lds = mvq_lds_bytes(threads / 64, S0.units, L.red_floats);
+  if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0 || L.nseg < 1 || L.nseg > 3) return hipErrorInvalidValue;
+  int n4 = 0, n6 = 0;
+  for (int i = 0; i < L.nseg; i++) {   // the launch-uniform geometry travels as preloaded scalars
+    const MvSeg& Si = L.seg[i];
+    if (Si.T != S0.T || Si.G != S0.G || Si.units != S0.units || Si.nblk != S0.nblk || Si.rows_per_wg != S0.rows_per_wg ||
+        (i > 0 && Si.wg_begin >= 0xFFFFu))
       return hipErrorInvalidValue;
+    if (Si.type == kDevQ4K_T16) n4++;
+    else if (Si.type == kDevQ6K_T16) n6++;
+    else return hipErrorInvalidValue;
+  }
   const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
   if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return hipErrorInvalidValue;
-  const uint64_t offA64 = (uint64_t)(S0.rows_per_wg / 16) * S0.nblk * kTileBytes;
-  if (offA64 > 0xFFFFFFFFull) return hipErrorInvalidValue;
   const uint32_t wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
   const uint32_t geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
   const uint32_t geom2 = S0.nblk | Rg << 16;
-  const uint32_t offA = (uint32_t)offA64, offB = Rg * S0.nblk * kTileBytes, offC = S0.units * kTileBytes;
-  hipLaunchKernelGGL(mvq_kernel, dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, offA, offB, offC,
-                     mvq_red_offset(threads / 64, S0.units), L);
-  return hipGetLastError();
+  const uint32_t red_off = mvq_red_offset(threads / 64, S0.units);
+  if (n6 == 0) return mvq_go<0>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+  if (n4 == 0) return mvq_go<1>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+  return mvq_go<2>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
 }
 
 }  // namespace lgh

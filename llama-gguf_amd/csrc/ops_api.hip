@@ -238,9 +238,9 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
 #ifdef LGH_STAMPS
   {  // phase profile of the LAST launch: per stamp, min / median / max over workgroups, relative to the first start
     std::vector<unsigned long long> st(8192 * 8);
-    if ((Ws[0].type == kDevQ4K_T16 ? lgh::mvq_read_stamps(st.data(), st.size()) : lgh::mv_read_stamps(st.data(), st.size())) == hipSuccess) {
+    if ((mfma_type(Ws[0].type) ? lgh::mvq_read_stamps(st.data(), st.size()) : lgh::mv_read_stamps(st.data(), st.size())) == hipSuccess) {
       MvPlan plan;
-      if (Ws[0].type == kDevQ4K_T16) (void)mvq_plan((uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n);
+      if (mfma_type(Ws[0].type)) (void)mvq_plan((uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n);
       else (void)mv_plan(Ws[0].type, (uint32_t)k, (uint32_t)n, mode == 2 ? 2 : 1, &plan, (uint32_t)n, 0);
       size_t nwg = std::min<size_t>(plan.n_wg, 8192);
       unsigned long long t0 = ~0ull;
@@ -253,7 +253,7 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
         std::sort(v.begin(), v.end());
         std::fprintf(stderr, "    %-16s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f\n", names[i], v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
       }
-      if (Ws[0].type == kDevQ4K_T16) {
+      if (mfma_type(Ws[0].type)) {
         unsigned long long sp[128];
         if (lgh::mvq_spans(sp, 0) == hipSuccess) {   // consecutive launches: busy span and idle gap between them
           std::vector<double> busy, idle;
