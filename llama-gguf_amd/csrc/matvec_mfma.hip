@@ -251,11 +251,17 @@ template <int FMT>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  // the position word (RoPE epilogues): its scalar load goes out with the very first kernarg loads, no wait here
+  const int* L_pos = L.pos;
+  uint32_t pos_now;
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pos_now) : "s"(L_pos) : "memory");
   const uint32_t bid = blockIdx.x;
   const int s = (int)(bid >= (wbpack & 0xFFFFu)) + (int)(bid >= (wbpack >> 16));   // 0xFFFF = no such segment
   const MvSeg& S = L.seg[s];
-  const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin;
-  const int S_npass = S.npass;
+  const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin, S_head_dim = S.head_dim;
+  const int S_npass = S.npass, S_epi = S.epi;
+  const float* S_resid = S.resid;
+  const float* L_rope_cs = L.rope_cs;
   const bool is_q6 = FMT == 1 || (FMT == 2 && S.type == kDevQ6K_T16);
   const uint32_t tb = is_q6 ? (uint32_t)kTileBytesQ6 : (uint32_t)kTileBytes;
   const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x7FFFu;
@@ -321,6 +327,10 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     }
   }
   const float* L_norm_w = nrm ? L.norm_w : nullptr;
+  MvEpiPre epi_pre = {0.0f, 0.0f, false};
+  mv_epilogue_prefetch_resid(S_epi, S_resid, S_nrows, wg, S_rpw, epi_pre);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pos_now));   // long since there: the kernarg batch above was waited for
+  mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
   struct Pos { uint32_t p, tl, b; };
   auto issue = [&](const Pos& q, RawT16& r) {   // five loads per tile in either format (the vmcnt bookkeeping counts on it)
@@ -508,7 +518,6 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
       x_request();
 #pragma unroll
       for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
-      LGH_WSTAMP(3);
       x_finish(n_first);
       LGH_WSTAMP(5);
       if constexpr (NF < kDepth) {   // that was everything
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue(L, S, wg, red, ssq, S_T);
+  mv_epilogue(L, S, wg, red, ssq, S_T, epi_pre);
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);

@@ -7,10 +7,43 @@ namespace lgh {
 
 __device__ __forceinline__ float silu_f(float g) { return g / (1.0f + expf(-g)); }
 
+// Operands of the epilogue that do not depend on the mat-vec — the residual element, or RoPE's cos/sin at the current
+// position — can be fetched at kernel START and carried in two registers: loaded after the final barrier they are a
+// dependent chain of global loads (position -> table index -> cos/sin) of ~1.5 us on the critical path.
+struct MvEpiPre { float a, b; bool valid; };
+
+// The residual element: issued first thing (one load, older than everything else in the wave's queue).  `epi` and
+// `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
+__device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, uint32_t n_rows, uint32_t wg,
+                                                           uint32_t rows_per_wg, MvEpiPre& pre) {
+  if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
+    const uint32_t t = threadIdx.x, row = wg * rows_per_wg + t;
+    if (t < rows_per_wg && row < n_rows) {
+      pre.a = resid[row];
+      pre.valid = true;
+    }
+  }
+}
+// RoPE's cos/sin at the current position (`pos` already in a scalar register).  Like the residual it must be issued
+// BEFORE the input vector and the weight tiles: a conditional load issued after them makes the compiler's wait for the
+// input vector conservative (it then also waits for the first tile to arrive from HBM).
+__device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos, const float* rope_cs, uint32_t head_dim,
+                                                          uint32_t n_rows, uint32_t wg, uint32_t rows_per_wg, MvEpiPre& pre) {
+  if (epi == EPI_ROPE_Q || epi == EPI_ROPE_K) {
+    const uint32_t rl = 2 * threadIdx.x, row = wg * rows_per_wg + rl;
+    if (rl < rows_per_wg && row < n_rows) {
+      const uint32_t half = head_dim / 2, i = (row % head_dim) / 2;
+      pre.a = rope_cs[((size_t)pos * half + i) * 2];
+      pre.b = rope_cs[((size_t)pos * half + i) * 2 + 1];
+      pre.valid = true;
+    }
+  }
+}
+
 // Per-row epilogue, one thread per row (or per row pair for RoPE)
 // `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
 __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
-                                            const float* ssq, uint32_t nslots) {
+                                            const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false}) {
   const uint32_t t = threadIdx.x;
   const uint32_t rbase = wg * S.rows_per_wg;
   float inv = 1.0f;
@@ -31,7 +64,8 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     if (S.bias) { x0 += S.bias[row]; x1 += S.bias[row + 1]; }
     const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim, half = d / 2;
     const uint32_t head = row / d, i = (row % d) / 2;
-    const float c = L.rope_cs[((size_t)pos * half + i) * 2], s = L.rope_cs[((size_t)pos * half + i) * 2 + 1];
+    const float c = pre.valid ? pre.a : L.rope_cs[((size_t)pos * half + i) * 2];
+    const float s = pre.valid ? pre.b : L.rope_cs[((size_t)pos * half + i) * 2 + 1];
     float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
     if (S.epi == EPI_ROPE_Q) {
       S.out[row] = y0;
@@ -50,7 +84,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   if (S.bias) v0 += S.bias[row];
   switch (S.epi) {
     case EPI_STORE: S.out[row] = v0; break;
-    case EPI_RESID: S.out[row] = v0 + S.resid[row]; break;
+    case EPI_RESID: S.out[row] = v0 + (pre.valid ? pre.a : S.resid[row]); break;
     case EPI_SWIGLU: {
       float up = rowval(1, t);
       S.out[row] = silu_f(v0) * up;
@@ -72,7 +106,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     case EPI_MOE_DOWN: {
       float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
       for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
-      S.out[row] = acc + S.resid[row];
+      S.out[row] = acc + (pre.valid ? pre.a : S.resid[row]);
       break;
     }
     default: break;
