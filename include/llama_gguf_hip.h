@@ -115,8 +115,10 @@ enum {
   LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
   LGH_SYM_ROUTER = 13,
   LGH_SYM_OTHER = 14,
-  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel : Q4_K mat-vec on the int8 matrix cores */
-  LGH_SYM_COUNT = 16
+  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<0> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
+  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<1> : ... every matrix Q6_K */
+  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<2> : ... Q4_K and Q6_K matrices in one launch (fused QKV of the _M mixes) */
+  LGH_SYM_COUNT = 20
 };
 
 typedef struct lgh_stats {

@@ -258,7 +258,12 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
     if (plan.red_floats > L.red_floats) L.red_floats = plan.red_floats;
   }
   alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
-  if (mfma) return run_k(c, cls, LGH_SYM_MVQ_Q4K, alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
+  if (mfma) {
+    int n6 = 0;
+    for (int s = 0; s < nseg; s++) n6 += L.seg[s].type == kDevQ6K_T16;
+    const int sym = n6 == 0 ? LGH_SYM_MVQ_Q4K : n6 == nseg ? LGH_SYM_MVQ_Q6K : LGH_SYM_MVQ_MIXED;
+    return run_k(c, cls, sym, alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
+  }
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
 }
 
@@ -338,6 +343,10 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
     return rc;
   // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
   if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo))) return rc;
+  if (c->profiling) {  // an EMPTY event bracket in mid-stream: what the measurement itself adds to every sample (at the
+    // head of a token, on an idle stream, the same bracket reads differently from run to run)
+    if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
+  }
   // ---- FFN
   if (!Lw.moe()) {
     if (fused_type(Lw.gate.type) && Lw.gate.type == Lw.up.type) {  // FeedForward::forward (layers.rs:908-929)
@@ -394,9 +403,6 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
 static int enqueue_token(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   int rc;
-  if (c->profiling) {  // an empty event bracket: what the measurement itself costs on this stream
-    if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
-  }
   if (c->first) {
     if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
            return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, c->stream);

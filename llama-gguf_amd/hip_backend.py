@@ -32,11 +32,12 @@ ABI_SYMBOLS = (
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
 K_COUNT = 16
+SYM_COUNT = 20
 # kernel symbols as rocprofv3 prints them (LGH_SYM_* order)
 SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_kernel<16u, 1024>",
              "lgh::mv_kernel<2u, 512>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
-             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel")
+             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<0>", "lgh::mvq_kernel<1>", "lgh::mvq_kernel<2>", "", "")
 FLAG_NO_GRAPH = 1
 
 
@@ -67,8 +68,8 @@ class Stats(C.Structure):
                 ("tokens_processed", C.c_uint64), ("graph_nodes", C.c_uint64),
                 ("k_launches", C.c_uint64 * K_COUNT), ("k_time_us", C.c_double * K_COUNT),
                 ("k_alg_bytes", C.c_uint64 * K_COUNT),
-                ("sym_launches", C.c_uint64 * K_COUNT), ("sym_time_us", C.c_double * K_COUNT),
-                ("sym_alg_bytes", C.c_uint64 * K_COUNT), ("step_alg_bytes", C.c_uint64),
+                ("sym_launches", C.c_uint64 * SYM_COUNT), ("sym_time_us", C.c_double * SYM_COUNT),
+                ("sym_alg_bytes", C.c_uint64 * SYM_COUNT), ("step_alg_bytes", C.c_uint64),
                 ("event_bracket_us", C.c_double), ("event_bracket_samples", C.c_uint64)]
 
 

@@ -69,7 +69,7 @@ def main():
         st = {short(r["Name"]): r for r in csv.DictReader(f)}
     lines = [f"# {tag}: measurement summary", "",
              f"bench: {bench['value']} {bench['unit']}, {bench['ms_per_step']} ms/token, n_gpus={bench['n_gpus']}", "",
-             "| kernel | rocprof calls | rocprof avg us | share % | bench avg us (hipEvent, bracket removed) | FETCH raw KB | WRITE raw KB | HBM bytes/launch (corrected) |",
+             "| kernel | rocprof calls | rocprof avg us | share % | bench avg us (hipEvent, bracket removed, + dispatch gap) | FETCH raw KB | WRITE raw KB | HBM bytes/launch (corrected) |",
              "|---|---|---|---|---|---|---|---|"]
     traffic = {r[0]: r for r in rows}
     for k, r in st.items():
@@ -78,7 +78,7 @@ def main():
         b = bench.get("kernels", {}).get(k, {})
         bavg = ""
         if b:
-            bavg = f"{b['avg_us'] - rl.get('event_bracket_us', 0.0):.2f}"
+            bavg = f"{b['avg_us'] - rl.get('event_bracket_us', 0.0) + rl.get('dispatch_gap_us', 0.0):.2f}"
         t = traffic.get(k)
         lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {r['Percentage']} | {bavg} | "
                      f"{t[2]:.0f} | {t[4]:.0f} | {t[5] / 1e6:.2f} MB |" if t else
