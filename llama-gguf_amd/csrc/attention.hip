@@ -18,6 +18,7 @@
 // The reference CPU path skips softmax weights <= 1e-8 (ops.rs:1529); like the reference's own GPU
 // kernel this one does not (each skipped term is < 1e-8 of the output scale).
 #include "device_utils.h"
+#include "xq.h"
 
 namespace lgh {
 
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
 // (all loads of a phase are independent and in flight together: the kernel is two memory round trips long).
 __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
                                                            uint32_t g_per_kv, uint32_t head_dim, uint32_t n_splits,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, uint8_t* __restrict__ xq_out) {
   __shared__ float s_f[64];
   __shared__ float s_linv;
   const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
@@ -142,7 +143,9 @@ __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restri
     float a = 0.0f;
 #pragma unroll 8
     for (uint32_t s = 0; s < n_splits; s++) a += part_acc[(p0 + (size_t)s * g_per_kv) * head_dim + dim] * s_f[s];
-    out[(size_t)h * head_dim + dim] = a * s_linv;
+    const float o = a * s_linv;
+    out[(size_t)h * head_dim + dim] = o;
+    if (xq_out) xq_store_chunk(xq_out, (h * head_dim + dim) >> 4, o);   // wo's input as XQ records (head_dim % 16 == 0)
   }
 }
 
@@ -170,10 +173,10 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
 }
 
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
-                               uint32_t head_dim, uint32_t n_splits, float* out, hipStream_t st) {
-  if (n_kv == 0 || n_heads % n_kv) return hipErrorInvalidValue;
+                               uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || head_dim % 16) return hipErrorInvalidValue;
   hipLaunchKernelGGL(attn_combine_kernel, dim3(n_heads), dim3(head_dim >= 128 ? 128 : 64), 0, st, part_ml, part_acc,
-                     n_heads / n_kv, head_dim, n_splits, out);
+                     n_heads / n_kv, head_dim, n_splits, out, xq_out);
   return hipGetLastError();
 }
 

@@ -95,7 +95,8 @@ enum MvEpilogue : int {
 
 struct MvPass {
   const uint8_t* plane[4];
-  const float* x;
+  const float* x;            // f32 input vector (VALU kernel)
+  const uint8_t* xq;         // the same vector as XQ records (xq.h; int8-MFMA kernel)
   const int* sel;            // optional device int: expert index; plane[i] += *sel * sel_stride[i]
   uint64_t sel_stride[4];
 };
@@ -118,6 +119,10 @@ struct MvSeg {
   const float* moe_w;        // device: routing weights of the selected experts
   uint32_t head_dim;         // RoPE / cache epilogues
   uint32_t max_seq;
+  // optional: also leave the output vector as XQ records for an int8-MFMA consumer (store / residual / SwiGLU epilogues)
+  uint8_t* xq_out;           // XQ image of `out` (n_rows must be a multiple of 16)
+  const float* xq_nw;        // the consumer's RMSNorm weights: records hold out * xq_nw, and ...
+  float* xq_ssq;             // ... xq_ssq[row / 16] = sum of out^2 over the chunk
 };
 
 struct MvLaunch {
@@ -129,6 +134,8 @@ struct MvLaunch {
   const int* pos;            // device: current position (RoPE / cache epilogues)
   const float* rope_cs;      // [max_seq][head_dim/2][2] cos,sin
   uint32_t red_floats;       // LDS floats for per-row partial sums (max over segments)
+  const float* ssq_part;     // int8-MFMA kernel with do_norm: partial sums of x^2 left by the producer of x
+  uint32_t n_ssq_part;
   uint32_t dbg_slot;         // diagnostic builds: launch sequence number mod 64 (span stamps)
   MvSeg seg[3];
 };
@@ -150,6 +157,7 @@ int mv_symbol(const MvLaunch& L);
 hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
+hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
 hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
                              float eps, const float* resid, hipStream_t st);
@@ -178,7 +186,7 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
                        uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, int kv_len_fixed,
                        uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
-                               uint32_t head_dim, uint32_t n_splits, float* out, hipStream_t st);
+                               uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
 
 // device state block: [0] token, [1] current position, [2] next position, [3] last arg-max
 enum { ST_TOKEN = 0, ST_POS = 1, ST_NEXT = 2, ST_ARGMAX = 3, ST_WORDS = 8 };

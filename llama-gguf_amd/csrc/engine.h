@@ -23,6 +23,10 @@ struct LayerW {
 
 enum TokenMode { MODE_PREFILL = 0, MODE_FORWARD = 1, MODE_GREEDY = 2, MODE_COUNT = 3 };
 
+// The XQ image (xq.h) of an f32 activation buffer, for int8-MFMA consumers.  `fresh` = the image matches the buffer's
+// current contents; `tag` = the RMSNorm weights it was multiplied with (nullptr: none).
+struct XqBuf { const float* f32 = nullptr; uint8_t* xq = nullptr; float* ssq = nullptr; uint32_t k = 0; bool fresh = false; const float* tag = nullptr; };
+
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
 }  // namespace lgh
@@ -58,6 +62,7 @@ struct lgh_ctx {
   lgh_stats stats{};
   std::vector<lgh::ProfRec> prof;
   std::vector<void*> allocs;  // everything hipMalloc'ed by this context
+  std::vector<lgh::XqBuf> xqs;
 };
 
 // ---- helpers shared by engine.hip and ops_api.hip ----
@@ -72,6 +77,9 @@ struct LayoutInfo {
 
 struct SegSpec {
   int npass = 1;
+  // also leave `out` as an XQ image for the next (int8-MFMA) consumer: 0 no, 1 plain, 2 multiplied by xq_next_nw (+ sum of squares)
+  int xq_next = 0;
+  const float* xq_next_nw = nullptr;
   const lgh::DevWeight* W[4] = {nullptr, nullptr, nullptr, nullptr};
   const float* x[4] = {nullptr, nullptr, nullptr, nullptr};
   const int* sel[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -91,8 +99,10 @@ int upload_matrix(lgh_ctx* c, lgh::DevWeight& W, int src_type, uint32_t k, uint3
                   const void* host, size_t nbytes);
 int upload_f32(lgh_ctx* c, float** dst, int src_type, uint64_t n, const void* host, size_t nbytes);
 int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k);
+lgh::XqBuf* xq_get(lgh_ctx* c, const float* f32, uint32_t k);   // finds or registers (allocating) the image of a buffer
+void xq_stale(lgh_ctx* c, const float* f32);
 int linear_any(lgh_ctx* c, int cls, const lgh::DevWeight& W, const float* x, float* out, const float* norm_w,
-               const float* resid, const float* bias);
+               const float* resid, const float* bias, int xq_next = 0, const float* xq_next_nw = nullptr);
 int drain_prof(lgh_ctx* c);
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 //                                                            arg-max back on device
 //   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
 #include "engine.h"
+#include "xq.h"
 
 #include <algorithm>
 #include <cmath>
@@ -202,6 +203,28 @@ int drain_prof(lgh_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 // fused mat-vec launch assembly
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// XQ images of activation buffers (xq.h)
+// ------------------------------------------------------------------------------------------------
+XqBuf* xq_get(lgh_ctx* c, const float* f32, uint32_t k) {
+  for (auto& q : c->xqs)
+    if (q.f32 == f32 && q.k >= k) return &q;
+  XqBuf q;
+  q.f32 = f32;
+  q.k = k;
+  if (dev_alloc(c, (void**)&q.xq, xq_bytes(k)) || dev_alloc(c, (void**)&q.ssq, (size_t)(k / 16 + 64) * 4)) return nullptr;
+  c->xqs.push_back(q);
+  return &c->xqs.back();
+}
+static XqBuf* xq_find(lgh_ctx* c, const float* f32) {
+  for (auto& q : c->xqs)
+    if (q.f32 == f32) return &q;
+  return nullptr;
+}
+void xq_stale(lgh_ctx* c, const float* f32) {
+  if (XqBuf* q = xq_find(c, f32)) q->fresh = false;
+}
+
 static uint32_t g_launch_seq = 0;   // diagnostic builds: consecutive launches get consecutive span slots
 static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma) {
   MvLaunch L;
@@ -248,9 +271,39 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
       for (int i = 0; i < 4; i++) { S.pass[p].plane[i] = W.plane[i]; S.pass[p].sel_stride[i] = W.stack_stride[i]; }
       S.pass[p].x = sp.x[p];
       S.pass[p].sel = sp.sel[p];
+      if (mfma) {   // the input vector as XQ records: left by its producer, or converted here
+        XqBuf* q = xq_get(c, sp.x[p], k);
+        if (!q) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
+        if (!q->fresh || q->tag != norm_w) {
+          int rq = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)k * 4, [&] {
+            return xq_quantize_launch(sp.x[p], norm_w, q->xq, norm_w ? q->ssq : nullptr, k, c->stream);
+          });
+          if (rq) return rq;
+          q->fresh = true;
+          q->tag = norm_w;
+        }
+        S.pass[p].xq = q->xq;
+        if (norm_w) { L.ssq_part = q->ssq; L.n_ssq_part = k / 16; }
+      }
       alg += W.bytes;
     }
     S.out = sp.out; S.out2 = sp.out2; S.resid = sp.resid; S.bias = sp.bias; S.moe_w = sp.moe_w;
+    {  // XQ image of the output for the next consumer, where this epilogue can write one
+      XqBuf* qo = sp.out ? xq_find(c, sp.out) : nullptr;
+      const bool can = sp.xq_next && qo && W0.n % 16 == 0 && W0.n <= qo->k && plan.rows_per_wg % 16 == 0 &&   // thread t <-> row t, chunk-aligned
+                      
+                       (sp.epi == EPI_STORE || sp.epi == EPI_RESID || sp.epi == EPI_SWIGLU || sp.epi == EPI_MOE_DOWN);
+      if (can) {
+        S.xq_out = qo->xq;
+        S.xq_nw = sp.xq_next == 2 ? sp.xq_next_nw : nullptr;
+        S.xq_ssq = sp.xq_next == 2 ? qo->ssq : nullptr;
+        qo->fresh = true;
+        qo->tag = S.xq_nw;
+      } else if (qo && sp.epi != EPI_ROPE_K && sp.epi != EPI_V_CACHE) {
+        qo->fresh = false;
+      }
+      if (sp.out2) xq_stale(c, sp.out2);
+    }
     S.head_dim = c->d.head_dim;
     S.max_seq = c->d.max_seq_len;
     wg += plan.n_wg;
@@ -284,14 +337,16 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
 
 // one Linear with optional norm prologue / residual epilogue, any device type
 int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* out, const float* norm_w,
-                      const float* resid, const float* bias) {
+                      const float* resid, const float* bias, int xq_next, const float* xq_next_nw) {
   if (fused_type(W.type)) {
     SegSpec sp;
     sp.W[0] = &W; sp.x[0] = x;
     sp.epi = resid ? EPI_RESID : EPI_STORE;
     sp.out = out; sp.resid = resid; sp.bias = bias;
+    sp.xq_next = xq_next; sp.xq_next_nw = xq_next_nw;
     return launch_mv(c, cls, &sp, 1, norm_w, W.k);
   }
+  xq_stale(c, out);
   if (bias) return fail(c, LGH_UNSUPPORTED, "bias on a non-quantized linear layer is not supported");
   return run_k(c, cls, LGH_SYM_F32_MATVEC, (uint64_t)W.n * W.k * 4, [&] {
     return f32_matvec_launch((const float*)W.plane[0], x, out, W.k, W.n, norm_w, c->d.norm_eps, resid, c->stream);
@@ -301,7 +356,9 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
 // ------------------------------------------------------------------------------------------------
 // one transformer layer (TransformerLayer::forward serial-residual branch, layers.rs:1187-1244)
 // ------------------------------------------------------------------------------------------------
-static int layer_forward(lgh_ctx* c, uint32_t li) {
+// `next_nw` / `next_mfma`: the norm weights and kernel family of whatever consumes this layer's output (the next layer's
+// QKV, or the output projection)
+static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool next_mfma) {
   LayerW& Lw = c->layers[li];
   const lgh_model_desc& d = c->d;
   const uint32_t H = d.hidden_size;
@@ -320,6 +377,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wq, c->hidden, c->q, Lw.attn_norm, nullptr, Lw.bq))) return rc;
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wk, c->hidden, kt, Lw.attn_norm, nullptr, Lw.bk))) return rc;
     if ((rc = linear_any(c, LGH_K_QKV, Lw.wv, c->hidden, vt, Lw.attn_norm, nullptr, Lw.bv))) return rc;
+    xq_stale(c, c->q);
     if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] {
            return rope_launch(c->q, kt, d.num_heads, d.num_kv_heads, d.head_dim, c->state + ST_POS, c->rope_cs, (int)d.use_neox_rope, c->stream);
          })))
@@ -337,12 +395,19 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
                             c->state + ST_POS, 0, c->n_splits, c->part_ml, c->part_acc, c->stream);
        })))
     return rc;
-  if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
-         return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out, c->stream);
-       })))
-    return rc;
+  {
+    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;   // wo's input as XQ, straight from the merge
+    if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
+           return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out,
+                                      qa ? qa->xq : nullptr, c->stream);
+         })))
+      return rc;
+    if (qa) { qa->fresh = true; qa->tag = nullptr; }
+    else xq_stale(c, c->attn_out);
+  }
   // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
-  if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo))) return rc;
+  const bool ffn_mfma = Lw.moe() ? mfma_type(Lw.gate_exps.type) : mfma_type(Lw.gate.type);
+  if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
   if (c->profiling) {  // an EMPTY event bracket in mid-stream: what the measurement itself adds to every sample (at the
     // head of a token, on an idle stream, the same bracket reads differently from run to run)
     if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
@@ -356,13 +421,15 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
       sp.x[0] = sp.x[1] = c->hidden;
       sp.epi = EPI_SWIGLU;
       sp.out = c->act;
+      sp.xq_next = mfma_type(Lw.down.type) ? 1 : 0;
       if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
     } else {
       if ((rc = linear_any(c, LGH_K_GATEUP, Lw.gate, c->hidden, c->act, Lw.ffn_norm, nullptr, nullptr))) return rc;
       if ((rc = linear_any(c, LGH_K_GATEUP, Lw.up, c->hidden, c->act2, Lw.ffn_norm, nullptr, nullptr))) return rc;
       if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return silu_mul_launch(c->act, c->act2, c->act, Lw.gate.n, c->stream); }))) return rc;
+      xq_stale(c, c->act);
     }
-    return linear_any(c, LGH_K_DOWN, Lw.down, c->act, c->hidden, nullptr, c->hidden, nullptr);
+    return linear_any(c, LGH_K_DOWN, Lw.down, c->act, c->hidden, nullptr, c->hidden, nullptr, next_mfma ? 2 : 0, next_nw);
   }
   // ---- MoE (moe.rs:321-413): router + top-k on device, experts selected by device-side index
   const uint32_t topk = d.num_experts_per_token;
@@ -394,6 +461,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li) {
     }
     sp.epi = EPI_MOE_DOWN;
     sp.out = c->hidden; sp.resid = c->hidden; sp.moe_w = c->moe_w;
+    sp.xq_next = next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
     if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
   }
   return LGH_OK;
@@ -411,8 +479,21 @@ static int enqueue_token(lgh_ctx* c, int mode) {
   } else {
     if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
   }
-  for (uint32_t li = c->l0; li < c->l1; li++)
-    if ((rc = layer_forward(c, li))) return rc;
+  for (auto& q : c->xqs) q.fresh = false;   // the residual stream was just (re)written in f32 (embedding / previous stage)
+  for (uint32_t li = c->l0; li < c->l1; li++) {
+    // who consumes this layer's output: the next layer's QKV (attn_norm), the output projection (output_norm), or — at a
+    // pipeline-stage boundary and at the end of a prefill step — nobody on this device
+    const float* next_nw = nullptr;
+    bool next_mfma = false;
+    if (li + 1 < c->l1) {
+      next_nw = c->layers[li + 1].attn_norm;
+      next_mfma = mfma_type(c->layers[li + 1].wq.type);
+    } else if (c->last && mode != MODE_PREFILL) {
+      next_nw = c->output_norm;
+      next_mfma = mfma_type(c->output.type);
+    }
+    if ((rc = layer_forward(c, li, next_nw, next_mfma))) return rc;
+  }
   if (c->last && mode != MODE_PREFILL) {
     // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
     if ((rc = linear_any(c, LGH_K_OUTPUT, c->output, c->hidden, c->logits, c->output_norm, nullptr, nullptr))) return rc;
@@ -678,6 +759,10 @@ int lgh_finalize(lgh_ctx* c) {
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
   }
+  // XQ images of the vectors that feed quantized mat-vecs (allocated here, never during a graph capture)
+  if (!xq_get(c, c->hidden, d.hidden_size) || !xq_get(c, c->attn_out, d.num_heads * d.head_dim) || !xq_get(c, c->act, (uint32_t)ffn) ||
+      !xq_get(c, c->act2, (uint32_t)ffn))
+    return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
   {
     // RoPE table in the reference's own arithmetic (ops.rs:1303-1313): libm powf / cosf / sinf on the host
     const uint32_t half = d.head_dim / 2;

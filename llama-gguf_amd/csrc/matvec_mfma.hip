@@ -25,6 +25,7 @@
 
 #include "device_utils.h"
 #include "mv_epilogue.h"
+#include "xq.h"
 
 namespace lgh {
 
@@ -180,53 +181,22 @@ hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_ro
 // ------------------------------------------------------------------------------------------------
 struct RawT16 { u32x4 hd; u32x4 q[4]; };
 
-__device__ __forceinline__ float wave_max_all(float v) {  // max over the 64 lanes, in every lane
-  v = fmaxf(v, dpp_f<0xB1>(v));
-  v = fmaxf(v, dpp_f<0x4E>(v));
-  v = fmaxf(v, dpp_f<0x141>(v));
-  v = fmaxf(v, dpp_f<0x140>(v));
-  float r = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)),
-                  __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)));
-  r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)));
-  r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48)));
-  return r;
+// ------------------------------------------------------------------------------------------------
+// stand-alone f32 -> XQ conversion (xq.h): for vectors whose producer cannot write XQ itself (the token embedding, the
+// per-op API, pipeline-stage inputs).  One thread per element; with `nw` the record holds x * nw and ssq_part[chunk]
+// receives each 16-element chunk's sum of x^2 (the RMSNorm prologue of the consumer).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) xq_quantize_kernel(const float* __restrict__ x, const float* __restrict__ nw,
+                                                          uint8_t* __restrict__ xq, float* __restrict__ ssq_part, uint32_t k) {
+  const uint32_t e = blockIdx.x * 256 + threadIdx.x;   // k is a multiple of 256
+  const float v = x[e];
+  xq_store_chunk(xq, e >> 4, nw ? v * nw[e] : v, ssq_part, v);
 }
 
-// One 256-element block of x -> limbs / sub-block sums / scale in LDS.  Called by a whole wave: lane i owns
-// elements 4i..4i+3 of the block.
-__device__ __forceinline__ void stage_block(f32x4 v, uint32_t blk, uint32_t lane, int8_t* limbs, float* xsum, float* xs16, float* sxs) {
-  const float amax = wave_max_all(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-  uint32_t e = (__float_as_uint(amax) >> 23) & 0xFFu;       // biased exponent: amax in [2^(e-127), 2^(e-126))
-  e = e < 30u ? 30u : (e > 250u ? 250u : e);                 // vanishing / overflowing blocks: clamp (|x'| stays < 1)
-  // x' = x * 2^-(e-126) lies in (-1, 1); I = rint(x' * 2^30) is an int32 with |I| <= 2^30.  Balanced base-256 digits
-  // of I (each in [-128, 127], top digit in [-64, 64]) are the four int8 limbs:  adding 0x00808080 biases the three low
-  // bytes by +128 with the carries landing where they belong, and the XOR takes the bias back out byte-wise
-  // (u - 128 as a signed byte is u ^ 0x80).  I = d3*2^24 + d2*2^16 + d1*2^8 + d0 exactly.
-  const float sc30 = __uint_as_float((283u - e) << 23);      // 2^-(e-126) * 2^30
-  uint32_t w[4];
-  const float xin[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int I = (int)__builtin_rintf(xin[k] * sc30);
-    w[k] = ((uint32_t)I + 0x00808080u) ^ 0x00808080u;
-  }
-  // 4x4 byte transpose: element-major words -> one word per limb holding this lane's 4 consecutive elements
-  const uint32_t t0 = __builtin_amdgcn_perm(w[1], w[0], 0x05010400u), t1 = __builtin_amdgcn_perm(w[1], w[0], 0x07030602u);
-  const uint32_t u0 = __builtin_amdgcn_perm(w[3], w[2], 0x05010400u), u1 = __builtin_amdgcn_perm(w[3], w[2], 0x07030602u);
-  const uint32_t limb[4] = {__builtin_amdgcn_perm(u1, t1, 0x07060302u),    // d3: most significant, limb row 0
-                            __builtin_amdgcn_perm(u1, t1, 0x05040100u),    // d2
-                            __builtin_amdgcn_perm(u0, t0, 0x07060302u),    // d1
-                            __builtin_amdgcn_perm(u0, t0, 0x05040100u)};   // d0
-  const uint32_t g = lane >> 3, kin = (lane & 7) * 4;        // sub-block and offset inside it
-#pragma unroll
-  for (int i = 0; i < 4; i++) *reinterpret_cast<uint32_t*>(limbs + ((size_t)(blk * 8 + g) * 4 + i) * 32 + kin) = limb[i];
-  float gs = (v.x + v.y) + (v.z + v.w);                      // f32 sum of the sub-block's x (reference: x_acc, simd.rs:1002-1008)
-  gs += dpp_f<0xB1>(gs);
-  gs += dpp_f<0x4E>(gs);                                     // the 4 lanes of a 16-element chunk (Q6_K's scale granularity)
-  if ((lane & 3) == 0) xs16[blk * 16 + ((lane >> 2) & 3) * 4 + (lane >> 4)] = gs;   // chunk j = lane/4 at [j & 3][j >> 2]
-  gs += dpp_f<0x141>(gs);                                    // row_half_mirror: the 8 lanes of a sub-block
-  if ((lane & 7) == 0) xsum[(blk * 2 + (g & 1)) * 4 + (g >> 1)] = gs;   // layout [blk][mq = g&1][p = g>>1]
-  if (lane == 0) sxs[blk] = __uint_as_float((e + 1u - 30u) << 23);      // s * 2^-30,  s = 2^(e-126)
+hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st) {
+  if (k == 0 || k % 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(xq_quantize_kernel, dim3(k / 256), dim3(256), 0, st, x, nw, xq, ssq_part, k);
+  return hipGetLastError();
 }
 
 constexpr int kWaves = 8;   // waves per workgroup: 2 per SIMD, 256 VGPRs each
@@ -261,6 +231,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin, S_head_dim = S.head_dim;
   const int S_npass = S.npass, S_epi = S.epi;
   const float* S_resid = S.resid;
+  const float* S_xq_nw = S.xq_nw;
   const float* L_rope_cs = L.rope_cs;
   const bool is_q6 = FMT == 1 || (FMT == 2 && S.type == kDevQ6K_T16);
   const uint32_t tb = is_q6 ? (uint32_t)kTileBytesQ6 : (uint32_t)kTileBytes;
@@ -282,42 +253,36 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const uint32_t ntiles = (S_nrows + 15) >> 4;
   const uint32_t tile0 = (wg * S_G + rg) * Rg;
   uint32_t ntile_w = active && tile0 < ntiles ? min(Rg, ntiles - tile0) : 0;
-  // LDS: per-wave private region, 1136 B per block of its k-slice: limbs 1024 | 32-element sums 32 | 16-element sums 64 |
-  // scale 4 (+12 pad); then the partial-sum slots and the per-wave sum(x^2)
+  // LDS: per-wave private copies of the XQ records of its k-slice (1280 B per block, xq.h), then the partial-sum slots
+  // and the total sum(x^2)
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem8;   // LDS byte address
-  const uint32_t wreg = wave * nbw * 1136u;
-  int8_t* limbs = reinterpret_cast<int8_t*>(smem8 + wreg);
-  const uint32_t limbs_lds = lds_base + wreg;
-  float* xsum = reinterpret_cast<float*>(smem8 + wreg + nbw * 1024u);
-  float* xs16 = reinterpret_cast<float*>(smem8 + wreg + nbw * 1056u);
-  float* sxs = reinterpret_cast<float*>(smem8 + wreg + nbw * 1120u);
+  const uint32_t wreg = wave * nbw * kXqRecord;
+  const uint8_t* xrec = smem8 + wreg;
+  const uint32_t xrec_lds = lds_base + wreg;
   float* red = reinterpret_cast<float*>(smem8 + lds_red_off);
   float* ssq = red + L_red_floats;
-  // lane roles inside an MFMA
-  const uint32_t n = lane & 15, c = lane >> 4;                    // B: weight row n, k-chunk c; D: row n, limb quad mq = c
-  const uint32_t sh = (c >> 1) * 4;                               // c>=2 lanes take the high nibbles
+  // lane roles inside an MFMA: B operand = weight row n, k-chunk c (16 elements); the A operand is block-diagonal over the
+  // four k-chunks — rows 4c'..4c'+3 = the four limbs of chunk c' — because XQ scales every 16 elements; so lane group
+  // mq = c of D holds the limb sums of chunk c of weight row n
+  const uint32_t n = lane & 15, c = lane >> 4;
+  const uint32_t sh = (c >> 1) * 4;                               // Q4_K: c>=2 lanes take the high nibbles
   const uint32_t lane_off_q = ((c & 1) * 16 + n) * 16, lane_off_hd = 2048 + n * 16;
-  // A operand: rows m = lane&15: m<4 -> limb m of sub-block 2p (k-chunks 0,1); m in 4..7 -> limb m-4 of sub-block 2p+1
-  const bool a_valid = n < 8 && (n >> 2) == (c >> 1);
-  const uint32_t a_off = ((c >> 1) * 4 + (n & 3)) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
-  const uint32_t mq = c;                                          // D lanes with mq < 2 hold sub-block 2p + mq
-  // Q6_K scales every 16 elements, so its A operand is block-diagonal over the FOUR k-chunks: rows 4c'..4c'+3 = the limbs
-  // of chunk c', and lane group mq = c of D holds the limb sums of chunk c of row n
-  const bool a_valid6 = (n >> 2) == c;
-  const uint32_t a_off6 = (c >> 1) * 128 + (n & 3) * 32 + (c & 1) * 16;   // + (b*8 + 2p) * 128
+  const bool a_valid = (n >> 2) == c;
+  const uint32_t a_off = (c >> 1) * 128 + (n & 3) * 32 + (c & 1) * 16;   // + b * 1280 + 2p * 128
+  const uint32_t mq = c;
 
   // per-pass base of this wave's tiles and input vector.  The MoE expert index is a SCALAR load — a vector load would
   // sit in the same in-order queue as the weight tiles.
   const uint64_t woff = ((uint64_t)tile0 * S_nblk + blk0) * tb;
   const uint8_t* pb[4] = {nullptr, nullptr, nullptr, nullptr};
-  const float* P_x[4] = {nullptr, nullptr, nullptr, nullptr};
+  const uint8_t* P_x[4] = {nullptr, nullptr, nullptr, nullptr};
 #pragma unroll
   for (int p = 0; p < 4; p++) {
     if (p < S_npass) {
       const MvPass& P = S.pass[p];
       const uint8_t* plane = P.plane[0];
       const int* sel = P.sel;
-      P_x[p] = P.x;
+      P_x[p] = P.xq;
       if (sel) {
         uint32_t e32;
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(sel) : "memory");
@@ -326,9 +291,18 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
       pb[p] = plane + woff;
     }
   }
-  const float* L_norm_w = nrm ? L.norm_w : nullptr;
+  // RMSNorm: the producer of x left partial sums of x^2; wave 0 gathers up to 256 of them now (oldest loads of the wave,
+  // first used after the last tile) and the rest, if any, at the end
+  const float* L_ssq_part = L.ssq_part;
+  const uint32_t L_n_ssq = L.n_ssq_part;
+  float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (nrm && wave == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (lane + 64 * j < L_n_ssq) ssp[j] = L_ssq_part[lane + 64 * j];
+  }
   MvEpiPre epi_pre = {0.0f, 0.0f, false};
-  mv_epilogue_prefetch_resid(S_epi, S_resid, S_nrows, wg, S_rpw, epi_pre);
+  mv_epilogue_prefetch_resid(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pos_now));   // long since there: the kernarg batch above was waited for
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
@@ -354,159 +328,115 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   auto advance = [&]() {
     if (++nx.b == nblk_w) { nx.b = 0; if (++nx.tl == ntile_w) { nx.tl = 0; ++nx.p; } }
   };
-  float ss = 0.0f;   // sum of squares of this wave's slice of x (RMSNorm prologue; row-group 0 covers all of x)
   float acc = 0.0f;
 
-  auto finish_tile = [&](const Pos& q) {   // last block of a (pass, tile): lane groups -> one partial sum per row
+  auto finish_tile = [&](const Pos& q) {   // last block of a (pass, tile): the four lane groups -> one partial sum per row
     float t = acc + __shfl_xor(acc, 16, 64);
-    if (is_q6) t += __shfl_xor(t, 32, 64);   // Q4_K: groups 0,1 carry the row; Q6_K: all four
+    t += __shfl_xor(t, 32, 64);
     if (mq == 0) red[(size_t)(q.p * S_T + ks) * S_rpw + (rg * Rg + q.tl) * 16 + n] = t;
     acc = 0.0f;
   };
-  auto consume4 = [&](const Pos& q, const RawT16& r) {
-    // this block's x limbs, sub-block sums and scale: written by this same wave (LDS ops of a wave execute in order)
-    i32x4 areg[4];
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-      i32x4 t = {0, 0, 0, 0};
-      if (a_valid) t = *reinterpret_cast<const i32x4*>(limbs + (size_t)(q.b * 8 + 2 * pp) * 128 + a_off);
-      areg[pp] = t;
-    }
-    const f32x4 xs4 = *reinterpret_cast<const f32x4*>(xsum + (q.b * 2 + (mq & 1)) * 4);
-    const float sxb = sxs[q.b];
-    // 6-bit scales / mins of sub-blocks mq, mq+2, mq+4, mq+6 of row n (packing: dequant.rs:210-223)
-    const uint32_t s8 = (mq & 1) * 8;
-    const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
-    const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
-    const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
-    const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
-    const float scf[4] = {ub0(sc01), ub2(sc01), ub0(sc23), ub2(sc23)};
-    const float mnf[4] = {ub0(mn01), ub2(mn01), ub0(mn23), ub2(mn23)};
-    float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-      i32x4 bw;
-      bw.x = (int)((r.q[pp].x >> sh) & 0x0F0F0F0Fu);
-      bw.y = (int)((r.q[pp].y >> sh) & 0x0F0F0F0Fu);
-      bw.z = (int)((r.q[pp].z >> sh) & 0x0F0F0F0Fu);
-      bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
-      const i32x4 zero = {0, 0, 0, 0};
-      const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
-      // lanes mq<2: d = limb sums of sub-block 2pp+mq for row n.  V = D0*2^24 + D1*2^16 + D2*2^8 + D3; both halves
-      // are exact in f32 (|D0| <= 64*480, |D1..3| <= 128*480, so |(Da<<8)+Db| < 2^24)
-      const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
-      const float V = __builtin_fmaf(hi, 65536.0f, lo);
-      s1 = __builtin_fmaf(scf[pp], V, s1);
-      s2 = __builtin_fmaf(mnf[pp], xs4[pp], s2);
-    }
-    const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
-    acc += (dd * sxb) * s1 - dmin * s2;
-    if (q.b + 1 == nblk_w) finish_tile(q);
-  };
-
-  auto consume6 = [&](const Pos& q, const RawT16& r) {
-    i32x4 areg[4];
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-      i32x4 t = {0, 0, 0, 0};
-      if (a_valid6) t = *reinterpret_cast<const i32x4*>(limbs + (size_t)(q.b * 8 + 2 * pp) * 128 + a_off6);
-      areg[pp] = t;
-    }
-    const f32x4 xs = *reinterpret_cast<const f32x4*>(xs16 + q.b * 16 + c * 4);   // sums of x over chunk 4pp + c
-    const float sxb = sxs[q.b];
-    const uint32_t s8 = c * 8;
-    const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};   // int8 scales 4pp .. 4pp+3 of row n (dequant.rs:343-350)
-    float s1 = 0.0f;
-#pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-      const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
-      const uint32_t H = pp == 0 ? r.q[2].x : pp == 1 ? r.q[2].y : pp == 2 ? r.q[2].z : r.q[2].w;
-      i32x4 bw;   // q' = ql | qh << 4, 0..63; the reference's "- 32" is applied through the chunk's sum of x below
-      bw.x = (int)((N0 & 0x0F0F0F0Fu) | ((H & 0x03030303u) << 4));
-      bw.y = (int)(((N0 >> 4) & 0x0F0F0F0Fu) | (((H >> 2) & 0x03030303u) << 4));
-      bw.z = (int)((N1 & 0x0F0F0F0Fu) | (((H >> 4) & 0x03030303u) << 4));
-      bw.w = (int)(((N1 >> 4) & 0x0F0F0F0Fu) | (((H >> 6) & 0x03030303u) << 4));
-      const i32x4 zero = {0, 0, 0, 0};
-      const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
-      // lane group mq: d = limb sums of chunk 4pp + mq for row n  (|D0| <= 64*63*16, so the high half is exact in f32;
-      // the low half may round at 2^-24 of a term that is itself 2^-16 of the sum)
-      const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
-      const float V = __builtin_fmaf(hi, 65536.0f, lo);
-      const float scf = (float)(int)__builtin_amdgcn_sbfe((int)hdw[pp], s8, 8);
-      s1 = __builtin_fmaf(scf, __builtin_fmaf(sxb, V, -32.0f * xs[pp]), s1);
-    }
-    const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
-    acc = __builtin_fmaf(h2f(dh), s1, acc);
-    if (q.b + 1 == nblk_w) finish_tile(q);
-  };
+  // one item = 16 weight rows x 256 elements.  Both formats: four MFMAs (one per 64 elements); lane group c then holds,
+  // for weight row n, the four limb sums of chunk 4pp + c, recombined to V = sum_k q_k * I_k (exact int, rounded once to f32).
   auto consume = [&](const Pos& q, const RawT16& r) {
-    if (is_q6) consume6(q, r);
-    else consume4(q, r);
+    const uint8_t* rec = xrec + q.b * kXqRecord;
+    i32x4 areg[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      i32x4 t = {0, 0, 0, 0};
+      if (a_valid) t = *reinterpret_cast<const i32x4*>(rec + pp * 256 + a_off);
+      areg[pp] = t;
+    }
+    const f32x4 xs = *reinterpret_cast<const f32x4*>(rec + kXqXs16 + c * 16);   // sum of x over chunk 4pp + c
+    const f32x4 sx = *reinterpret_cast<const f32x4*>(rec + kXqSx16 + c * 16);   // its scale * 2^-30
+    if (is_q6) {
+      const uint32_t s8 = c * 8;
+      const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};   // int8 scales 4pp .. 4pp+3 of row n (dequant.rs:343-350)
+      float s1 = 0.0f;
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) {
+        const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+        const uint32_t H = pp == 0 ? r.q[2].x : pp == 1 ? r.q[2].y : pp == 2 ? r.q[2].z : r.q[2].w;
+        i32x4 bw;   // q' = ql | qh << 4, 0..63; the reference's "- 32" is applied through the chunk's sum of x below
+        bw.x = (int)((N0 & 0x0F0F0F0Fu) | ((H & 0x03030303u) << 4));
+        bw.y = (int)(((N0 >> 4) & 0x0F0F0F0Fu) | (((H >> 2) & 0x03030303u) << 4));
+        bw.z = (int)((N1 & 0x0F0F0F0Fu) | (((H >> 4) & 0x03030303u) << 4));
+        bw.w = (int)(((N1 >> 4) & 0x0F0F0F0Fu) | (((H >> 6) & 0x03030303u) << 4));
+        const i32x4 zero = {0, 0, 0, 0};
+        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
+        // |D0| <= 64*63*16, so the high half is exact in f32; the low half may round at 2^-24 of a term that is 2^-16 of the sum
+        const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+        const float V = __builtin_fmaf(hi, 65536.0f, lo);
+        const float scf = (float)(int)__builtin_amdgcn_sbfe((int)hdw[pp], s8, 8);
+        s1 = __builtin_fmaf(scf, __builtin_fmaf(sx[pp], V, -32.0f * xs[pp]), s1);
+      }
+      const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
+      acc = __builtin_fmaf(h2f(dh), s1, acc);
+    } else {
+      // 6-bit scales / mins of sub-blocks h, h+2, h+4, h+6 of row n, h = c >> 1 (packing: dequant.rs:210-223); chunk
+      // 4pp + c lies in sub-block 2pp + h
+      const uint32_t s8 = (c >> 1) * 8;
+      const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
+      const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
+      const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
+      const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
+      const float scf[4] = {ub0(sc01), ub2(sc01), ub0(sc23), ub2(sc23)};
+      const float mnf[4] = {ub0(mn01), ub2(mn01), ub0(mn23), ub2(mn23)};
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) {
+        i32x4 bw;
+        bw.x = (int)((r.q[pp].x >> sh) & 0x0F0F0F0Fu);
+        bw.y = (int)((r.q[pp].y >> sh) & 0x0F0F0F0Fu);
+        bw.z = (int)((r.q[pp].z >> sh) & 0x0F0F0F0Fu);
+        bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
+        const i32x4 zero = {0, 0, 0, 0};
+        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
+        // both halves exact in f32: |D0| <= 64*15*16, |D1..3| <= 128*15*16
+        const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+        const float V = __builtin_fmaf(hi, 65536.0f, lo);
+        s1 = __builtin_fmaf(scf[pp] * sx[pp], V, s1);
+        s2 = __builtin_fmaf(mnf[pp], xs[pp], s2);   // the reference's x_acc per sub-block (simd.rs:1002-1008), split per chunk
+      }
+      const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
+      acc += dd * s1 - dmin * s2;
+    }
+    if (q.b + 1 == nblk_w) finish_tile(q);
   };
 
-  auto x_of = [&](int p) { return p == 0 ? P_x[0] : p == 1 ? P_x[1] : p == 2 ? P_x[2] : P_x[3]; };
+  auto x_of = [&](int p) -> const uint8_t* { return p == 0 ? P_x[0] : p == 1 ? P_x[1] : p == 2 ? P_x[2] : P_x[3]; };
   for (int p0 = 0; p0 < S_npass;) {   // phases: runs of passes that share one input vector
     int p1 = p0 + 1;
     while (p1 < S_npass && x_of(p1) == x_of(p0)) p1++;
     const uint32_t npp = (uint32_t)(p1 - p0);
-    const float* xg = x_of(p0) + (size_t)blk0 * 256;   // this wave's k-slice
-    const float* nwg = L_norm_w + (size_t)blk0 * 256;
+    const uint8_t* xg = x_of(p0) + (size_t)blk0 * kXqRecord;   // this wave's k-slice of XQ records
     nx.p = (uint32_t)p0; nx.tl = 0; nx.b = 0;
     // Opaque to the optimizer (the values do not change): otherwise every shape's loop-invariant bookkeeping — ~300
     // scalar instructions, most of them for paths not taken — is hoisted in front of the first load, at 1.7 ns each.
     asm volatile("" : "+s"(nblk_w), "+s"(ntile_w));
     const uint32_t nitems = npp * ntile_w * nblk_w;
 
-    // ---- x staging.  x_request goes out FIRST, the caller's tile issues right behind it; loads return in order, so
-    // x_finish waits for x alone (vmcnt = the weight loads behind it) and converts while the tiles are in flight.
-    f32x4 xv0, wv0, xv1, wv1;
-    const uint32_t b1 = nblk_w > 1 ? 1u : 0u;   // clamped, so the second request is unconditional (exact vmcnt bookkeeping)
+    // ---- x staging: the wave's XQ records go straight into its LDS region by LDS-DMA (1024 B + 256 B per record, no
+    // registers, no vector ALU), requested FIRST; the caller's tile issues follow, loads return in order, so x_finish
+    // waits for x alone (vmcnt = the weight loads behind it).  Inline asm: with the builtin hipcc drains vmcnt to 0 at
+    // the next load it issues.
     auto x_request = [&]() {
-      if (!nrm) {
-        // plain input: LDS-DMA, 1 KiB per wave-instruction straight into the block's LDS region, no registers.
-        // (Inline asm: with the builtin hipcc drains vmcnt to 0 at the next load it issues.)
-        for (uint32_t b = 0; b < nblk_w; b++) {
-          const float* src = xg + b * 256 + lane * 4;
-          const uint32_t dst = limbs_lds + b * 1024;
-          uint32_t keep;
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-        }
-      } else {
-        xv0 = reinterpret_cast<const f32x4*>(xg)[lane];
-        wv0 = reinterpret_cast<const f32x4*>(nwg)[lane];
-        xv1 = reinterpret_cast<const f32x4*>(xg)[b1 * 64 + lane];
-        wv1 = reinterpret_cast<const f32x4*>(nwg)[b1 * 64 + lane];
+      for (uint32_t b = 0; b < nblk_w; b++) {
+        const uint8_t* src = xg + b * kXqRecord;
+        const uint32_t dst = xrec_lds + b * kXqRecord;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
       }
-    };
-    auto norm_block = [&](f32x4 v, f32x4 w, uint32_t b) {   // RMSNorm prologue: sum of squares of raw x, limbs of x * w
-      if (p0 == 0) {   // the norm belongs to the first input vector only
-        ss = __builtin_fmaf(v.x, v.x, ss);
-        ss = __builtin_fmaf(v.y, v.y, ss);
-        ss = __builtin_fmaf(v.z, v.z, ss);
-        ss = __builtin_fmaf(v.w, v.w, ss);
-      }
-      stage_block(v * w, b, lane, limbs, xsum, xs16, sxs);
     };
     auto x_finish = [&](auto n_tiles) {
       constexpr int NT = decltype(n_tiles)::value;
-      if (!nrm) {
-        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        LGH_WSTAMP(4);
-        for (uint32_t b = 0; b < nblk_w; b++) {
-          // the read precedes the limb stores into the same 1-KiB region (in-order LDS)
-          const f32x4 v = *reinterpret_cast<const f32x4*>(limbs + (size_t)b * 1024 + lane * 16);
-          stage_block(v, b, lane, limbs, xsum, xs16, sxs);
-        }
-      } else {
-        norm_block(xv0, wv0, 0);
-        if (nblk_w > 1) norm_block(xv1, wv1, 1);
-        for (uint32_t b = 2; b < nblk_w; b++)   // slices of more than two blocks (hidden sizes above 4096): behind the tiles
-          norm_block(reinterpret_cast<const f32x4*>(xg)[b * 64 + lane], reinterpret_cast<const f32x4*>(nwg)[b * 64 + lane], b);
-      }
+      if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+      else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      LGH_WSTAMP(4);
     };
 
     RawT16 buf[kDepth];
@@ -550,15 +480,6 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         for (uint32_t p = (uint32_t)p0; p < (uint32_t)p1; p++)
           for (uint32_t tl = 0; tl < ntile_w; tl++)
             if (mq == 0) red[(size_t)(p * S_T + ks) * S_rpw + (rg * Rg + tl) * 16 + n] = 0.0f;
-      } else if (nrm && p0 == 0 && nblk_w > 0 && rg == 0) {
-        // no tiles for this wave in this workgroup, but the norm still needs its slice's sum of squares
-        for (uint32_t b = 0; b < nblk_w; b++) {
-          const f32x4 v = reinterpret_cast<const f32x4*>(xg)[b * 64 + lane];
-          ss = __builtin_fmaf(v.x, v.x, ss);
-          ss = __builtin_fmaf(v.y, v.y, ss);
-          ss = __builtin_fmaf(v.z, v.z, ss);
-          ss = __builtin_fmaf(v.w, v.w, ss);
-        }
       }
     } else if (nitems == 1) {
       run(std::integral_constant<int, 1>{});
@@ -573,9 +494,13 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     LGH_STAMP(3);
     LGH_WSTAMP(6);
   }
-  if (nrm) {   // row-group 0 covers every block of x exactly once
+  if (nrm && wave == 0) {   // the producer's partial sums of x^2 -> ssq[0]; the other waves contribute nothing
+    float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
+    for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += L_ssq_part[i];
     ss = wave_sum_to_lane63(ss);
-    if (lane == 63) ssq[wave] = rg == 0 ? ss : 0.0f;
+    if (lane == 63) ssq[0] = ss;
+  } else if (nrm && lane == 0) {
+    ssq[wave] = 0.0f;
   }
   __syncthreads();
   LGH_STAMP(4);
@@ -615,7 +540,7 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   return hipSuccess;
 }
 
-static uint32_t mvq_red_offset(uint32_t nwaves, uint32_t nbw) { return nwaves * nbw * 1136u; }
+static uint32_t mvq_red_offset(uint32_t nwaves, uint32_t nbw) { return nwaves * nbw * kXqRecord; }
 size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }

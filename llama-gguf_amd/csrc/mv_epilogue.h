@@ -2,6 +2,7 @@
 #pragma once
 
 #include "device_utils.h"
+#include "xq.h"
 
 namespace lgh {
 
@@ -14,12 +15,13 @@ struct MvEpiPre { float a, b; bool valid; };
 
 // The residual element: issued first thing (one load, older than everything else in the wave's queue).  `epi` and
 // `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
-__device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, uint32_t n_rows, uint32_t wg,
+__device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, const float* xq_nw, uint32_t n_rows, uint32_t wg,
                                                            uint32_t rows_per_wg, MvEpiPre& pre) {
   if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
     const uint32_t t = threadIdx.x, row = wg * rows_per_wg + t;
     if (t < rows_per_wg && row < n_rows) {
       pre.a = resid[row];
+      pre.b = xq_nw ? xq_nw[row] : 1.0f;   // the next consumer's norm weight, for the XQ image of the output
       pre.valid = true;
     }
   }
@@ -82,12 +84,16 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   if (row >= S.n_rows) return;
   float v0 = rowval(0, t);
   if (S.bias) v0 += S.bias[row];
+  float outv = 0.0f;        // the value written to out[row] by the epilogues that can also leave an XQ image
+  bool has_out = false;
   switch (S.epi) {
-    case EPI_STORE: S.out[row] = v0; break;
-    case EPI_RESID: S.out[row] = v0 + (pre.valid ? pre.a : S.resid[row]); break;
+    case EPI_STORE: outv = v0; S.out[row] = outv; has_out = true; break;
+    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : S.resid[row]); S.out[row] = outv; has_out = true; break;
     case EPI_SWIGLU: {
       float up = rowval(1, t);
-      S.out[row] = silu_f(v0) * up;
+      outv = silu_f(v0) * up;
+      S.out[row] = outv;
+      has_out = true;
       break;
     }
     case EPI_V_CACHE: {
@@ -106,10 +112,21 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     case EPI_MOE_DOWN: {
       float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
       for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
-      S.out[row] = acc + (pre.valid ? pre.a : S.resid[row]);
+      outv = acc + (pre.valid ? pre.a : S.resid[row]);
+      S.out[row] = outv;
+      has_out = true;
       break;
     }
     default: break;
+  }
+  // ---- XQ image of the output for an int8-MFMA consumer (xq.h).  n_rows is a multiple of 16 here (host-checked), so the
+  // 16 threads of a chunk are all live; with a norm in front of the consumer the record holds out * norm_weight and each
+  // chunk leaves its sum of out^2.
+  uint8_t* xq = S.xq_out;
+  if (xq && has_out) {
+    const float* nw = S.xq_nw;
+    const float w = !nw ? 1.0f : (pre.valid && (S.epi == EPI_RESID || S.epi == EPI_MOE_DOWN)) ? pre.b : nw[row];
+    xq_store_chunk(xq, row >> 4, outv * w, S.xq_ssq, outv);
   }
 }
 

@@ -164,7 +164,7 @@ int lgh_op_attention_cached(int device, const float* q, const float* kc, const f
   if (attn_launch(dq, dk, dv, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)max_seq, scale, nullptr, (int)kv_len,
                   (uint32_t)n_splits, pml, pacc, t.c->stream) != hipSuccess)
     return LGH_UNSUPPORTED;
-  if (attn_combine_launch(pml, pacc, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)n_splits, dout, t.c->stream) != hipSuccess)
+  if (attn_combine_launch(pml, pacc, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)n_splits, dout, nullptr, t.c->stream) != hipSuccess)
     return LGH_OPERATION_FAILED;
   return t.down(out, dout, n_heads * d);
 }
