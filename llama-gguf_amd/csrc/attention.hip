@@ -37,7 +37,14 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t sub = lane / LPR, li = lane % LPR;
-  const uint32_t kv_len = pos_ptr ? (uint32_t)(*pos_ptr + 1) : (uint32_t)kv_len_fixed;
+  // the position word by SCALAR load: the loop bounds depend on it, and a vector load here would be a full memory round
+  // trip before the first K/V row can be requested
+  uint32_t kv_len = (uint32_t)kv_len_fixed;
+  if (pos_ptr) {
+    uint32_t pw;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
+    kv_len = pw + 1;
+  }
 
   f32x4 qv[G];
 #pragma unroll
@@ -51,12 +58,9 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
   const float* kbase = kc + (size_t)kvh * max_seq * D + li * 4;
   const float* vbase = vc + (size_t)kvh * max_seq * D + li * 4;
   const uint32_t stride = n_splits * 4 * RPW;
-  for (uint32_t base = (sp * 4 + wave) * RPW; base < kv_len; base += stride) {
-    const uint32_t p = base + sub;
-    const bool valid = p < kv_len;
-    const uint32_t pc = valid ? p : kv_len - 1;
-    const f32x4 k4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + (size_t)pc * D));
-    const f32x4 v4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + (size_t)pc * D));
+  auto row_of = [&](uint32_t base) { const uint32_t p = base + sub; return p < kv_len ? p : kv_len - 1; };   // clamped: loads are unconditional
+  auto step = [&](uint32_t base, f32x4 k4, f32x4 v4) {
+    const bool valid = base + sub < kv_len;
 #pragma unroll
     for (int g = 0; g < G; g++) {
       float s = qv[g].x * k4.x;
@@ -72,6 +76,22 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
       l[g] = __builtin_fmaf(l[g], a, pe);
       acc[g] = acc[g] * a + v4 * pe;
       m[g] = mn;
+    }
+  };
+  // two rows per lane group in flight: at decode lengths a workgroup has 2-3 iterations, each a full HBM / Infinity-Cache
+  // round trip if it is only requested after the previous one has been consumed
+  uint32_t base = (sp * 4 + wave) * RPW;
+  if (base < kv_len) {
+    f32x4 k0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + (size_t)row_of(base) * D));
+    f32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + (size_t)row_of(base) * D));
+    while (true) {
+      const uint32_t nb = base + stride;   // next iteration's rows, requested before this one is used (clamped when past the end)
+      const f32x4 k1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(kbase + (size_t)row_of(nb) * D));
+      const f32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(vbase + (size_t)row_of(nb) * D));
+      step(base, k0, v0);
+      if (nb >= kv_len) break;
+      base = nb;
+      k0 = k1; v0 = v1;
     }
   }
 
@@ -127,22 +147,29 @@ __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restri
   __shared__ float s_linv;
   const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
   const size_t p0 = (size_t)kvh * n_splits * g_per_kv + g;   // split s lives at p0 + s * g_per_kv
+  // every partial this thread will need is requested up front (one dim per thread: blockDim == head_dim <= 128), so the
+  // kernel is ONE memory round trip long instead of two dependent ones (m/l first, accumulators after the barrier)
+  const uint32_t dim = threadIdx.x;
+  float pa[32];
+#pragma unroll
+  for (uint32_t sidx = 0; sidx < 32; sidx++)
+    pa[sidx] = (sidx < n_splits && dim < head_dim) ? part_acc[(p0 + (size_t)sidx * g_per_kv) * head_dim + dim] : 0.0f;
   if (threadIdx.x < 64) {
-    const uint32_t s = threadIdx.x;
-    const bool ok = s < n_splits;
-    const float m = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2] : kNegBig;
-    const float l = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2 + 1] : 0.0f;
+    const uint32_t sidx = threadIdx.x;
+    const bool ok = sidx < n_splits;
+    const float m = ok ? part_ml[(p0 + (size_t)sidx * g_per_kv) * 2] : kNegBig;
+    const float l = ok ? part_ml[(p0 + (size_t)sidx * g_per_kv) * 2 + 1] : 0.0f;
     const float mn = wave_max(m);
     const float f = expf(m - mn);
     const float lsum = wave_sum(l * f);
-    s_f[s] = f;
-    if (s == 0) s_linv = 1.0f / lsum;  // simd.rs:718-720: multiply by 1/sum
+    s_f[sidx] = f;
+    if (sidx == 0) s_linv = 1.0f / lsum;  // simd.rs:718-720: multiply by 1/sum
   }
   __syncthreads();
-  for (uint32_t dim = threadIdx.x; dim < head_dim; dim += blockDim.x) {
+  if (dim < head_dim) {
     float a = 0.0f;
-#pragma unroll 8
-    for (uint32_t s = 0; s < n_splits; s++) a += part_acc[(p0 + (size_t)s * g_per_kv) * head_dim + dim] * s_f[s];
+#pragma unroll
+    for (uint32_t sidx = 0; sidx < 32; sidx++) a += pa[sidx] * s_f[sidx];   // s_f of absent splits is exp(-1e30 - m) = 0
     const float o = a * s_linv;
     out[(size_t)h * head_dim + dim] = o;
     if (xq_out) xq_store_chunk(xq_out, (h * head_dim + dim) >> 4, o);   // wo's input as XQ records (head_dim % 16 == 0)
@@ -174,8 +201,8 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
 
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
-  if (n_kv == 0 || n_heads % n_kv || head_dim % 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(n_heads), dim3(head_dim >= 128 ? 128 : 64), 0, st, part_ml, part_acc,
+  if (n_kv == 0 || n_heads % n_kv || head_dim % 16 || head_dim > 128 || n_splits > 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_combine_kernel, dim3(n_heads), dim3(head_dim > 64 ? 128 : 64), 0, st, part_ml, part_acc,
                      n_heads / n_kv, head_dim, n_splits, out, xq_out);
   return hipGetLastError();
 }

@@ -590,6 +590,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
     if (splits < 1) splits = 1;
     if (splits > 32) splits = 32;
   }
+  if (splits > 32) splits = 32;   // the split merge keeps one partial per split in registers
   c->n_splits = splits;
   *out = c;
   return LGH_OK;
