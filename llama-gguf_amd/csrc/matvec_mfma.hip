@@ -17,10 +17,11 @@
 // d*sc*s*2^-30; the min term uses f32 sums of x per sub-block, exactly as the reference's x_acc.
 // Error vs the reference's sequential f32 sum is below f32 rounding noise and independent of summation order.
 //
-// Device layout "tile16" (same bytes as GGUF, rows padded to 16): a tile = 16 rows x one 256-element block =
-// 2304 B:  [p=0..3][c'=0..1][row 0..15] 16-byte pieces qs_row[32p+16c' .. +16)  (2048 B), then the 16 native
-// 16-byte headers {d, dmin, scales[12]}.  Lane (n = l&15, c = l>>4) of a wave loads the piece (p, c&1, n): low
-// nibbles are sub-block 2p (c<2), high nibbles sub-block 2p+1 (c>=2), 16 consecutive elements each.
+// Device layout "tile16" (same bytes as GGUF, rows padded to 16): a tile = 16 rows x one 256-element block = 2304 B.
+// The nibbles of MFMA step pp (elements 64pp .. 64pp+63) and k-chunk c (16 elements) of row n belong to lane 16c + n,
+// eight bytes per step:  N0, N1 with byte t = w[t] | w[t+4] << 4  (w = elements 0-7 / 8-15 of the chunk), so B-operand
+// dwords are N0 & 0x0F.., N0 >> 4 & 0x0F.., N1 & 0x0F.., N1 >> 4 & 0x0F.. and every lane loads only its own nibbles:
+//   [0, 1024) lane-major 16 B: N0,N1 of steps 0,1    [1024, 2048) steps 2,3    [2048, 2304) the 16 native 16-byte headers
 #include <type_traits>
 
 #include "device_utils.h"
@@ -81,27 +82,41 @@ constexpr int kTileBytesQ6 = 3392;    // Q6_K tile16
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) repack_q4k_t16_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ dst,
                                                             uint32_t n_rows, uint32_t nblk, uint64_t total) {
+  // one thread per (row, block, step pp): idx = ((row * nblk) + b) * 4 + pp.  Elements 64pp .. 64pp+63 of the block live in
+  // qs[32pp .. 32pp+31]: low nibbles = the first 32, high nibbles = the second 32 (dequant.rs:232-255).
   for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
-    const uint32_t row = (uint32_t)(idx / nblk), b = (uint32_t)(idx % nblk);
+    const uint32_t pp = (uint32_t)(idx & 3);
+    const uint64_t rb = idx >> 2;
+    const uint32_t row = (uint32_t)(rb / nblk), b = (uint32_t)(rb % nblk);
     const uint32_t rt = row >> 4, n = row & 15;
     uint8_t* tile = dst + ((size_t)rt * nblk + b) * kTileBytes;
-    u32x4 hd = {0, 0, 0, 0}, piece[8];
+    const bool live = row < n_rows;
+    const uint8_t* src = raw + ((size_t)row * nblk + b) * 144;
 #pragma unroll
-    for (int i = 0; i < 8; i++) piece[i] = (u32x4){0, 0, 0, 0};
-    if (row < n_rows) {
-      const uint8_t* src = raw + ((size_t)row * nblk + b) * 144;
-      hd = *reinterpret_cast<const u32x4*>(src);
+    for (uint32_t c = 0; c < 4; c++) {
+      uint32_t w[16];
 #pragma unroll
-      for (int i = 0; i < 8; i++) piece[i] = *reinterpret_cast<const u32x4*>(src + 16 + 16 * i);  // i = 2p + c'
+      for (uint32_t t = 0; t < 16; t++) {
+        const uint32_t byte = live ? src[16 + 32 * pp + 16 * (c & 1) + t] : 0u;
+        w[t] = c < 2 ? (byte & 15u) : (byte >> 4);
+      }
+      uint32_t N0 = 0, N1 = 0;
+#pragma unroll
+      for (uint32_t t = 0; t < 4; t++) {
+        N0 |= (w[t] | w[t + 4] << 4) << (8 * t);
+        N1 |= (w[t + 8] | w[t + 12] << 4) << (8 * t);
+      }
+      uint32_t* nib = reinterpret_cast<uint32_t*>(tile + (pp >> 1) * 1024 + (16 * c + n) * 16 + (pp & 1) * 8);
+      nib[0] = N0;
+      nib[1] = N1;
     }
-    *reinterpret_cast<u32x4*>(tile + 2048 + n * 16) = hd;
-#pragma unroll
-    for (int i = 0; i < 8; i++) *reinterpret_cast<u32x4*>(tile + (i >> 1) * 512 + ((i & 1) * 16 + n) * 16) = piece[i];
+    // the native 16-byte header {d, dmin, scales[12]}, one dword per pp-thread
+    *reinterpret_cast<uint32_t*>(tile + 2048 + n * 16 + pp * 4) = live ? *reinterpret_cast<const uint32_t*>(src + pp * 4) : 0u;
   }
 }
 
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st) {
-  const uint64_t total = (uint64_t)((n_rows + 15) / 16) * 16 * nblk;
+  const uint64_t total = (uint64_t)((n_rows + 15) / 16) * 16 * nblk * 4;
   uint64_t blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(repack_q4k_t16_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, raw, dst, n_rows, nblk, total);
@@ -265,8 +280,6 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   // four k-chunks — rows 4c'..4c'+3 = the four limbs of chunk c' — because XQ scales every 16 elements; so lane group
   // mq = c of D holds the limb sums of chunk c of weight row n
   const uint32_t n = lane & 15, c = lane >> 4;
-  const uint32_t sh = (c >> 1) * 4;                               // Q4_K: c>=2 lanes take the high nibbles
-  const uint32_t lane_off_q = ((c & 1) * 16 + n) * 16, lane_off_hd = 2048 + n * 16;
   const bool a_valid = (n >> 2) == c;
   const uint32_t a_off = (c >> 1) * 128 + (n & 3) * 32 + (c & 1) * 16;   // + b * 1280 + 2p * 128
   const uint32_t mq = c;
@@ -274,23 +287,28 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   // per-pass base of this wave's tiles and input vector.  The MoE expert index is a SCALAR load — a vector load would
   // sit in the same in-order queue as the weight tiles.
   const uint64_t woff = ((uint64_t)tile0 * S_nblk + blk0) * tb;
-  const uint8_t* pb[4] = {nullptr, nullptr, nullptr, nullptr};
-  const uint8_t* P_x[4] = {nullptr, nullptr, nullptr, nullptr};
-#pragma unroll
-  for (int p = 0; p < 4; p++) {
+  // (four named scalars each, not arrays: an array indexed by the pass number ends up in scratch memory, and a kernel
+  // that touches scratch pays for it at every launch)
+  const uint8_t *pb0 = nullptr, *pb1 = nullptr, *pb2 = nullptr, *pb3 = nullptr;
+  const uint8_t *px0 = nullptr, *px1 = nullptr, *px2 = nullptr, *px3 = nullptr;
+  auto pass_setup = [&](int p, const uint8_t*& pb, const uint8_t*& px) {
     if (p < S_npass) {
       const MvPass& P = S.pass[p];
       const uint8_t* plane = P.plane[0];
       const int* sel = P.sel;
-      P_x[p] = P.xq;
+      px = P.xq;
       if (sel) {
         uint32_t e32;
         asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(e32) : "s"(sel) : "memory");
         plane += (uint64_t)e32 * P.sel_stride[0];
       }
-      pb[p] = plane + woff;
+      pb = plane + woff;
     }
-  }
+  };
+  pass_setup(0, pb0, px0);
+  pass_setup(1, pb1, px1);
+  pass_setup(2, pb2, px2);
+  pass_setup(3, pb3, px3);
   // RMSNorm: the producer of x left partial sums of x^2; wave 0 gathers up to 256 of them now (oldest loads of the wave,
   // first used after the last tile) and the rest, if any, at the end
   const float* L_ssq_part = L.ssq_part;
@@ -307,18 +325,18 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
   struct Pos { uint32_t p, tl, b; };
-  auto issue = [&](const Pos& q, RawT16& r) {   // five loads per tile in either format (the vmcnt bookkeeping counts on it)
-    const uint8_t* base = q.p == 0 ? pb[0] : q.p == 1 ? pb[1] : q.p == 2 ? pb[2] : pb[3];
+  auto issue = [&](const Pos& q, RawT16& r) {   // Q6_K: five loads per tile, Q4_K: three (x_finish counts on it)
+    const uint8_t* base = q.p == 0 ? pb0 : q.p == 1 ? pb1 : q.p == 2 ? pb2 : pb3;
     const uint8_t* tile = base + ((size_t)q.tl * S_nblk + q.b) * tb;
     if (is_q6) {
       r.hd = ldg_nt128(tile + 3072 + n * 16);
 #pragma unroll
       for (int i = 0; i < 3; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
       r.q[3].x = ldg_nt32(tile + 3328 + (n >> 1) * 4);
-    } else {
-      r.hd = ldg_nt128(tile + lane_off_hd);
-#pragma unroll
-      for (int pp = 0; pp < 4; pp++) r.q[pp] = ldg_nt128(tile + pp * 512 + lane_off_q);
+    } else {   // three loads
+      r.hd = ldg_nt128(tile + 2048 + n * 16);
+      r.q[0] = ldg_nt128(tile + lane * 16);
+      r.q[1] = ldg_nt128(tile + 1024 + lane * 16);
     }
   };
 
@@ -385,11 +403,12 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int pp = 0; pp < 4; pp++) {
+        const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
         i32x4 bw;
-        bw.x = (int)((r.q[pp].x >> sh) & 0x0F0F0F0Fu);
-        bw.y = (int)((r.q[pp].y >> sh) & 0x0F0F0F0Fu);
-        bw.z = (int)((r.q[pp].z >> sh) & 0x0F0F0F0Fu);
-        bw.w = (int)((r.q[pp].w >> sh) & 0x0F0F0F0Fu);
+        bw.x = (int)(N0 & 0x0F0F0F0Fu);
+        bw.y = (int)((N0 >> 4) & 0x0F0F0F0Fu);
+        bw.z = (int)(N1 & 0x0F0F0F0Fu);
+        bw.w = (int)((N1 >> 4) & 0x0F0F0F0Fu);
         const i32x4 zero = {0, 0, 0, 0};
         const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
         // both halves exact in f32: |D0| <= 64*15*16, |D1..3| <= 128*15*16
@@ -404,7 +423,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     if (q.b + 1 == nblk_w) finish_tile(q);
   };
 
-  auto x_of = [&](int p) -> const uint8_t* { return p == 0 ? P_x[0] : p == 1 ? P_x[1] : p == 2 ? P_x[2] : P_x[3]; };
+  auto x_of = [&](int p) -> const uint8_t* { return p == 0 ? px0 : p == 1 ? px1 : p == 2 ? px2 : px3; };
   for (int p0 = 0; p0 < S_npass;) {   // phases: runs of passes that share one input vector
     int p1 = p0 + 1;
     while (p1 < S_npass && x_of(p1) == x_of(p0)) p1++;
@@ -432,10 +451,18 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     };
     auto x_finish = [&](auto n_tiles) {
       constexpr int NT = decltype(n_tiles)::value;
-      if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-      else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      // n_tiles tiles x (5 | 3) loads were issued behind the x requests
+      if (is_q6) {
+        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else {
+        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      }
       LGH_WSTAMP(4);
     };
 
