@@ -271,7 +271,8 @@ def main():
     pkg = graft.load_package()
     from importlib import import_module
     pkg.pipeline = import_module("llama_gguf_amd.pipeline")
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # LGH_BENCH_FORCE_PIPELINE=1: run the N>1 code path with however many ranks there are (a 1-rank rehearsal on a 1-GPU box)
+    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LGH_BENCH_FORCE_PIPELINE"):
         run_pipeline(args, pkg)
     else:
         run_single(args, pkg)

@@ -115,9 +115,11 @@ enum {
   LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
   LGH_SYM_ROUTER = 13,
   LGH_SYM_OTHER = 14,
-  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<0> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
-  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<1> : ... every matrix Q6_K */
-  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<2> : ... Q4_K and Q6_K matrices in one launch (fused QKV of the _M mixes) */
+  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1u> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
+  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<2u> : ... every matrix Q6_K */
+  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
+  LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u> / <6u> : Q5_K (and Q5_K + Q6_K) */
+  LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u> / <16u> : Q8_0 / Q4_0 */
   LGH_SYM_COUNT = 20
 };
 

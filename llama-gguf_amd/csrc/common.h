@@ -43,7 +43,8 @@ __host__ __device__ inline uint32_t blk_bytes(int t) {
 
 constexpr int kDevQ4K_T16 = 1012;  // device-only type tag: Q4_K in the 16-row tile layout of matvec_mfma.hip
 constexpr int kDevQ6K_T16 = 1014;  // Q6_K in its 16-row tile layout (3392 B per tile), same kernel
-inline bool mfma_type(int t) { return t == kDevQ4K_T16 || t == kDevQ6K_T16; }
+constexpr int kDevQ5K_T16 = 1013, kDevQ80_T16 = 1008, kDevQ40_T16 = 1002;   // Q5_K (2816 B), Q8_0 (4352 B), Q4_0 (2304 B) tiles
+inline bool mfma_type(int t) { return t == kDevQ4K_T16 || t == kDevQ6K_T16 || t == kDevQ5K_T16 || t == kDevQ80_T16 || t == kDevQ40_T16; }
 
 // ---------------------------------------------------------------------------------------------
 // Device weight layouts (what lgh_upload_tensor leaves in HBM).  Byte counts equal the GGUF payload;
@@ -158,6 +159,7 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
+hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
 hipError_t f32_matvec_launch(const float* w, const float* x, float* out, uint32_t k, uint32_t n, const float* norm_w,
                              float eps, const float* resid, hipStream_t st);

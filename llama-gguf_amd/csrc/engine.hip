@@ -76,7 +76,7 @@ LayoutInfo layout_for(int src_type) {
 }
 
 bool fused_type(int t) {
-  return t == kDevQ4K_T16 || t == kDevQ6K_T16 || t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
+  return mfma_type(t) || t == LGH_TYPE_Q4_K || t == LGH_TYPE_Q5_K || t == LGH_TYPE_Q6_K || t == LGH_TYPE_Q8_0 || t == LGH_TYPE_Q4_0;
 }
 
 // Upload one matrix (or expert `slot` of a stack, or the whole stack when slot < 0) given in native
@@ -91,14 +91,19 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
   const uint32_t n_in_payload = slot < 0 ? n_stack : 1;
   if (nbytes != per_expert_src * n_in_payload) return fail(c, LGH_SHAPE_MISMATCH, "tensor byte size does not match its shape");
   uint64_t blocks_per_expert = (uint64_t)n * (k / li.belems);
-  const bool t16 = src_type == LGH_TYPE_Q4_K || src_type == LGH_TYPE_Q6_K;   // int8-MFMA tile layouts: rows padded to 16
+  // int8-MFMA tile layouts (16 rows x 256 elements, rows padded to 16) for the five fused formats when k allows it
+  const bool t16 = k % 256 == 0 && (src_type == LGH_TYPE_Q4_K || src_type == LGH_TYPE_Q6_K || src_type == LGH_TYPE_Q5_K ||
+                                    src_type == LGH_TYPE_Q8_0 || src_type == LGH_TYPE_Q4_0);
   if (t16) {
-    if (src_type == LGH_TYPE_Q4_K) {
-      li.dev_type = kDevQ4K_T16;                       // 2304 B per 16 rows x 256 elements
-    } else {
-      li.dev_type = kDevQ6K_T16;                       // 3392 B per tile: 212 B per row-block, one plane
-      li.nplanes = 1;
-      li.bpb[0] = 212; li.bpb[1] = li.bpb[2] = li.bpb[3] = 0;
+    li.nplanes = 1;
+    li.belems = 256;
+    li.bpb[1] = li.bpb[2] = li.bpb[3] = 0;
+    switch (src_type) {   // bytes per row-block = tile bytes / 16
+      case LGH_TYPE_Q4_K: li.dev_type = kDevQ4K_T16; li.bpb[0] = 144; break;
+      case LGH_TYPE_Q6_K: li.dev_type = kDevQ6K_T16; li.bpb[0] = 212; break;
+      case LGH_TYPE_Q5_K: li.dev_type = kDevQ5K_T16; li.bpb[0] = 176; break;
+      case LGH_TYPE_Q8_0: li.dev_type = kDevQ80_T16; li.bpb[0] = 272; break;
+      default: li.dev_type = kDevQ40_T16; li.bpb[0] = 144; break;
     }
     blocks_per_expert = (uint64_t)((n + 15) / 16) * 16 * (k / 256);
   }
@@ -138,9 +143,7 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
     if (li.dev_type == LGH_TYPE_F32) {
       e = dequant_launch(src_type, src, (float*)(W.plane[0] + (uint64_t)(e0 + i) * W.stack_stride[0]), (uint64_t)n * k, c->stream);
     } else if (t16) {
-      uint8_t* dstp = W.base + (uint64_t)(e0 + i) * W.stack_stride[0];
-      e = src_type == LGH_TYPE_Q4_K ? repack_q4k_t16_launch(src, dstp, n, k / 256, c->stream)
-                                    : repack_q6k_t16_launch(src, dstp, n, k / 256, c->stream);
+      e = repack_t16_launch(li.dev_type, src, W.base + (uint64_t)(e0 + i) * W.stack_stride[0], n, k / 256, c->stream);
     } else {
       uint64_t po[4];
       for (int p = 0; p < 4; p++) po[p] = (uint64_t)(W.plane[p] - W.base) + (uint64_t)(e0 + i) * W.stack_stride[p];
@@ -312,9 +315,13 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
   }
   alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
   if (mfma) {
-    int n6 = 0;
-    for (int s = 0; s < nseg; s++) n6 += L.seg[s].type == kDevQ6K_T16;
-    const int sym = n6 == 0 ? LGH_SYM_MVQ_Q4K : n6 == nseg ? LGH_SYM_MVQ_Q6K : LGH_SYM_MVQ_MIXED;
+    bool has[8] = {false, false, false, false, false, false, false, false};
+    for (int s = 0; s < nseg; s++) {
+      const int t = L.seg[s].type;
+      has[t == kDevQ4K_T16 ? 0 : t == kDevQ6K_T16 ? 1 : t == kDevQ5K_T16 ? 2 : t == kDevQ80_T16 ? 3 : 4] = true;
+    }
+    const int sym = has[2] ? LGH_SYM_MVQ_Q5K : (has[3] || has[4]) ? LGH_SYM_MVQ_Q80_Q40 : (has[0] && has[1]) ? LGH_SYM_MVQ_MIXED
+                    : has[1] ? LGH_SYM_MVQ_Q6K : LGH_SYM_MVQ_Q4K;
     return run_k(c, cls, sym, alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
   }
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
@@ -330,6 +337,20 @@ int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* 
     else b[nb++] = specs[s];
   }
   int rc = LGH_OK;
+  if (na > 1) {   // formats that have a common instantiation: Q4_K+Q6_K, Q5_K+Q6_K (the "_M" mixes); otherwise one launch each
+    bool q4 = false, q5 = false, other = false;
+    for (int s = 0; s < na; s++) {
+      const int t = a[s].W[0]->type;
+      q4 |= t == kDevQ4K_T16; q5 |= t == kDevQ5K_T16; other |= t == kDevQ80_T16 || t == kDevQ40_T16;
+    }
+    bool uniform = true;
+    for (int s = 1; s < na; s++) uniform &= a[s].W[0]->type == a[0].W[0]->type;
+    if (!uniform && ((q4 && q5) || other)) {
+      for (int s = 0; s < na; s++)
+        if ((rc = launch_mv_group(c, cls, a + s, 1, norm_w, k, true))) return rc;
+      na = 0;
+    }
+  }
   if (na && (rc = launch_mv_group(c, cls, a, na, norm_w, k, true))) return rc;
   if (nb && (rc = launch_mv_group(c, cls, b, nb, norm_w, k, false))) return rc;
   return rc;

@@ -76,6 +76,15 @@ hipError_t mvq_spans(unsigned long long* host, int reset) {
 
 constexpr int kTileBytes = 2304;      // Q4_K tile16
 constexpr int kTileBytesQ6 = 3392;    // Q6_K tile16
+// formats of the matrix-core mat-vec; a kernel instantiation handles the formats in its MASK (bit = 1 << format)
+enum : int { F_Q4K = 0, F_Q6K = 1, F_Q5K = 2, F_Q80 = 3, F_Q40 = 4, F_COUNT = 5 };
+__host__ __device__ constexpr uint32_t fmt_tile_bytes(int f) {   // = 16 rows x the GGUF bytes of 256 elements (Q6_K: +32 pad)
+  return f == F_Q4K ? 2304u : f == F_Q6K ? 3392u : f == F_Q5K ? 2816u : f == F_Q80 ? 4352u : 2304u;
+}
+__host__ __device__ constexpr int fmt_loads_per_tile(int f) { return f == F_Q4K ? 3 : f == F_Q6K ? 5 : f == F_Q5K ? 4 : f == F_Q80 ? 5 : 3; }
+__host__ __device__ constexpr int fmt_of_dev_type(int t) {
+  return t == kDevQ4K_T16 ? F_Q4K : t == kDevQ6K_T16 ? F_Q6K : t == kDevQ5K_T16 ? F_Q5K : t == kDevQ80_T16 ? F_Q80 : t == kDevQ40_T16 ? F_Q40 : -1;
+}
 
 // ------------------------------------------------------------------------------------------------
 // native [row][block] Q4_K  ->  tile16
@@ -197,6 +206,105 @@ hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_ro
 struct RawT16 { u32x4 hd; u32x4 q[4]; };
 
 // ------------------------------------------------------------------------------------------------
+// Q5_K, Q8_0, Q4_0 -> tile16.  Same lane mapping as above (step pp, k-chunk c, row n -> lane 16c + n).
+//   Q5_K (2816 B): the Q4_K tile (nibble words [0,2048), native headers [2048,2304)) + [2304,2816) lane-major 8 B: the fifth
+//         bits, one dword per step PAIR: byte t = f[t] | f[t+4]<<1 | f[t+8]<<2 | f[t+12]<<3 of the even step in the low
+//         nibble, of the odd step in the high nibble
+//   Q8_0 (4352 B): [pp][lane] 16 quants as they are (int8) [0,4096), then per row the 8 f16 d of its 32-element blocks
+//   Q4_0 (2304 B): nibble words [0,2048) as Q4_K (unsigned 0..15; the reference's "- 8" goes through the sums of x), then
+//         per row the 8 f16 d
+// One thread per (row, 256-element block, step).
+// ------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void __launch_bounds__(256) repack_t16_kernel(const uint8_t* __restrict__ raw, uint8_t* __restrict__ dst,
+                                                        uint32_t n_rows, uint32_t nblk, uint64_t total) {
+  constexpr uint32_t TB = fmt_tile_bytes(F);
+  constexpr uint32_t SRC = F == F_Q5K ? 176u : F == F_Q80 ? 8u * 34u : 8u * 18u;   // native bytes of 256 elements
+  for (uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * 256) {
+    const uint32_t pp = (uint32_t)(idx & 3);
+    const uint64_t rb = idx >> 2;
+    const uint32_t row = (uint32_t)(rb / nblk), b = (uint32_t)(rb % nblk);
+    const uint32_t rt = row >> 4, n = row & 15;
+    uint8_t* tile = dst + ((size_t)rt * nblk + b) * TB;
+    const bool live = row < n_rows;
+    const uint8_t* src = raw + ((size_t)row * nblk + b) * SRC;
+    auto quant = [&](uint32_t e) -> uint32_t {   // unsigned quant (Q8_0: the byte) of element e of the 256
+      if (!live) return 0u;
+      if (F == F_Q5K) {   // dequant.rs:265-316
+        const uint32_t g = e >> 6, w = e & 63, l = w & 31, is = 2 * g + (w >> 5);
+        const uint32_t byte = src[48 + g * 32 + l];
+        return (w < 32 ? (byte & 15u) : (byte >> 4)) | (((src[16 + l] >> is) & 1u) << 4);
+      }
+      const uint32_t sb = e >> 5, i = e & 31;   // 32-element block and offset
+      if (F == F_Q80) return src[sb * 34 + 2 + i];                       // dequant.rs:106-112
+      const uint32_t byte = src[sb * 18 + 2 + (i & 15)];               // Q4_0, dequant.rs:16-30
+      return i < 16 ? (byte & 15u) : (byte >> 4);
+    };
+    uint32_t hpair[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+      uint32_t w[16];
+#pragma unroll
+      for (uint32_t t = 0; t < 16; t++) w[t] = quant(64 * pp + 16 * c + t);
+      const uint32_t lane = 16 * c + n;
+      if (F == F_Q80) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(tile + pp * 1024 + lane * 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) q[j] = w[4 * j] | w[4 * j + 1] << 8 | w[4 * j + 2] << 16 | w[4 * j + 3] << 24;
+      } else {
+        uint32_t N0 = 0, N1 = 0, H = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 4; t++) {
+          N0 |= ((w[t] & 15u) | (w[t + 4] & 15u) << 4) << (8 * t);
+          N1 |= ((w[t + 8] & 15u) | (w[t + 12] & 15u) << 4) << (8 * t);
+          H |= ((w[t] >> 4) | (w[t + 4] >> 4) << 1 | (w[t + 8] >> 4) << 2 | (w[t + 12] >> 4) << 3) << (8 * t);
+        }
+        uint32_t* nib = reinterpret_cast<uint32_t*>(tile + (pp >> 1) * 1024 + lane * 16 + (pp & 1) * 8);
+        nib[0] = N0;
+        nib[1] = N1;
+        hpair[c] = H;
+      }
+    }
+    if (F == F_Q5K) {
+      // the fifth bits of this step go into the low (even step) or high (odd step) nibbles of the pair's dword: two
+      // threads (pp, pp^1) write disjoint nibbles of the same dword, so each does a byte-wise read-modify-write of ITS
+      // nibbles only -> use 4-bit-disjoint atomicOr on a zero-initialised destination
+#pragma unroll
+      for (uint32_t c = 0; c < 4; c++)
+        atomicOr(reinterpret_cast<uint32_t*>(tile + 2304 + (16 * c + n) * 8 + (pp >> 1) * 4), hpair[c] << (4 * (pp & 1)));
+      *reinterpret_cast<uint32_t*>(tile + 2048 + n * 16 + pp * 4) = live ? *reinterpret_cast<const uint32_t*>(src + pp * 4) : 0u;
+    } else {
+      // two f16 d per step thread: blocks 2pp, 2pp+1
+      const uint32_t bs = F == F_Q80 ? 34u : 18u, hoff = F == F_Q80 ? 4096u : 2048u;
+      uint32_t d2 = 0;
+      if (live) d2 = (uint32_t)(src[(2 * pp) * bs] | src[(2 * pp) * bs + 1] << 8) | (uint32_t)(src[(2 * pp + 1) * bs] | src[(2 * pp + 1) * bs + 1] << 8) << 16;
+      *reinterpret_cast<uint32_t*>(tile + hoff + n * 16 + pp * 4) = d2;
+    }
+  }
+}
+
+hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st) {
+  const uint64_t total = (uint64_t)((n_rows + 15) / 16) * 16 * nblk * 4;
+  uint64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  const dim3 g((uint32_t)blocks), t(256);
+  switch (fmt_of_dev_type(dev_type)) {
+    case F_Q4K: return repack_q4k_t16_launch(raw, dst, n_rows, nblk, st);
+    case F_Q6K: return repack_q6k_t16_launch(raw, dst, n_rows, nblk, st);
+    case F_Q5K: {
+      hipError_t e = hipMemsetAsync(dst, 0, (size_t)((n_rows + 15) / 16) * nblk * fmt_tile_bytes(F_Q5K), st);   // fifth bits are OR-ed in
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((repack_t16_kernel<F_Q5K>), g, t, 0, st, raw, dst, n_rows, nblk, total);
+      break;
+    }
+    case F_Q80: hipLaunchKernelGGL((repack_t16_kernel<F_Q80>), g, t, 0, st, raw, dst, n_rows, nblk, total); break;
+    case F_Q40: hipLaunchKernelGGL((repack_t16_kernel<F_Q40>), g, t, 0, st, raw, dst, n_rows, nblk, total); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // stand-alone f32 -> XQ conversion (xq.h): for vectors whose producer cannot write XQ itself (the token embedding, the
 // per-op API, pipeline-stage inputs).  One thread per element; with `nw` the record holds x * nw and ssq_part[chunk]
 // receives each 16-element chunk's sum of x^2 (the RMSNorm prologue of the consumer).
@@ -231,8 +339,8 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 //   * per-segment fields come from `L` in one batch of scalar loads, per-pass fields only for passes that exist.
 // geom  = T | G << 8 | nbw << 16 | do_norm << 31         geom2 = nblk | Rg << 16        wbpack = wg_begin[1] | wg_begin[2] << 16
 // offA/B/C = byte strides of a workgroup / a row-group / a k-slice inside one pass's tile array
-// FMT: 0 = every segment Q4_K, 1 = every segment Q6_K, 2 = mixed (the segment's type decides at run time)
-template <int FMT>
+// MASK: the formats (1 << F_*) the instantiation handles; with more than one the segment's type decides at run time
+template <uint32_t MASK>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
@@ -248,8 +356,11 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   const float* S_resid = S.resid;
   const float* S_xq_nw = S.xq_nw;
   const float* L_rope_cs = L.rope_cs;
-  const bool is_q6 = FMT == 1 || (FMT == 2 && S.type == kDevQ6K_T16);
-  const uint32_t tb = is_q6 ? (uint32_t)kTileBytesQ6 : (uint32_t)kTileBytes;
+  constexpr bool kSingle = (MASK & (MASK - 1)) == 0;
+  const int fmt = kSingle ? __builtin_ctz(MASK) : fmt_of_dev_type(S.type);
+  auto is = [&](int f) { return ((MASK >> f) & 1u) != 0 && (kSingle || fmt == f); };   // compile-time false for absent formats
+  const uint32_t tb = is(F_Q4K) ? fmt_tile_bytes(F_Q4K) : is(F_Q6K) ? fmt_tile_bytes(F_Q6K) : is(F_Q5K) ? fmt_tile_bytes(F_Q5K)
+                      : is(F_Q80) ? fmt_tile_bytes(F_Q80) : fmt_tile_bytes(F_Q40);
   const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x7FFFu;
   const bool nrm = (geom >> 31) != 0;
   const uint32_t S_nblk = geom2 & 0xFFFFu, Rg = geom2 >> 16;
@@ -325,18 +436,27 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
   struct Pos { uint32_t p, tl, b; };
-  auto issue = [&](const Pos& q, RawT16& r) {   // Q6_K: five loads per tile, Q4_K: three (x_finish counts on it)
+  auto issue = [&](const Pos& q, RawT16& r) {   // fmt_loads_per_tile(format) loads (x_finish counts on it)
     const uint8_t* base = q.p == 0 ? pb0 : q.p == 1 ? pb1 : q.p == 2 ? pb2 : pb3;
     const uint8_t* tile = base + ((size_t)q.tl * S_nblk + q.b) * tb;
-    if (is_q6) {
+    if (is(F_Q6K)) {
       r.hd = ldg_nt128(tile + 3072 + n * 16);
 #pragma unroll
       for (int i = 0; i < 3; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
       r.q[3].x = ldg_nt32(tile + 3328 + (n >> 1) * 4);
-    } else {   // three loads
+    } else if (is(F_Q80)) {
+      r.hd = ldg_nt128(tile + 4096 + n * 16);
+#pragma unroll
+      for (int i = 0; i < 4; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
+    } else {   // Q4_K, Q5_K, Q4_0: header + two nibble loads (+ the fifth bits)
       r.hd = ldg_nt128(tile + 2048 + n * 16);
       r.q[0] = ldg_nt128(tile + lane * 16);
       r.q[1] = ldg_nt128(tile + 1024 + lane * 16);
+      if (is(F_Q5K)) {
+        const u32x2 h = ldg_nt64(tile + 2304 + lane * 8);
+        r.q[2].x = h.x;
+        r.q[2].y = h.y;
+      }
     }
   };
 
@@ -367,7 +487,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     }
     const f32x4 xs = *reinterpret_cast<const f32x4*>(rec + kXqXs16 + c * 16);   // sum of x over chunk 4pp + c
     const f32x4 sx = *reinterpret_cast<const f32x4*>(rec + kXqSx16 + c * 16);   // its scale * 2^-30
-    if (is_q6) {
+    if (is(F_Q6K)) {
       const uint32_t s8 = c * 8;
       const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};   // int8 scales 4pp .. 4pp+3 of row n (dequant.rs:343-350)
       float s1 = 0.0f;
@@ -390,9 +510,34 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
       }
       const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
       acc = __builtin_fmaf(h2f(dh), s1, acc);
+    } else if (is(F_Q80) || is(F_Q40)) {
+      // 32-element blocks with one f16 scale: chunk 4pp + c lies in block 2pp + (c >> 1) of the row's eight
+      const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};
+      float s1 = 0.0f;
+#pragma unroll
+      for (int pp = 0; pp < 4; pp++) {
+        i32x4 bw;
+        if (is(F_Q80)) {
+          bw.x = (int)r.q[pp].x; bw.y = (int)r.q[pp].y; bw.z = (int)r.q[pp].z; bw.w = (int)r.q[pp].w;   // int8 quants as they are
+        } else {
+          const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+          bw.x = (int)(N0 & 0x0F0F0F0Fu);
+          bw.y = (int)((N0 >> 4) & 0x0F0F0F0Fu);
+          bw.z = (int)(N1 & 0x0F0F0F0Fu);
+          bw.w = (int)((N1 >> 4) & 0x0F0F0F0Fu);
+        }
+        const i32x4 zero = {0, 0, 0, 0};
+        const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
+        const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+        const float V = __builtin_fmaf(hi, 65536.0f, lo);
+        const float dd = h2f((c >> 1) ? hdw[pp] >> 16 : hdw[pp] & 0xFFFFu);
+        // Q4_0: y = d * (q - 8) (dequant.rs:16-30); the offset goes through the chunk's sum of x
+        s1 = __builtin_fmaf(dd, is(F_Q40) ? __builtin_fmaf(sx[pp], V, -8.0f * xs[pp]) : sx[pp] * V, s1);
+      }
+      acc += s1;
     } else {
-      // 6-bit scales / mins of sub-blocks h, h+2, h+4, h+6 of row n, h = c >> 1 (packing: dequant.rs:210-223); chunk
-      // 4pp + c lies in sub-block 2pp + h
+      // Q4_K / Q5_K: 6-bit scales / mins of sub-blocks h, h+2, h+4, h+6 of row n, h = c >> 1 (packing: dequant.rs:210-223);
+      // chunk 4pp + c lies in sub-block 2pp + h
       const uint32_t s8 = (c >> 1) * 8;
       const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
       const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
@@ -409,9 +554,16 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         bw.y = (int)((N0 >> 4) & 0x0F0F0F0Fu);
         bw.z = (int)(N1 & 0x0F0F0F0Fu);
         bw.w = (int)((N1 >> 4) & 0x0F0F0F0Fu);
+        if (is(F_Q5K)) {   // the fifth bit: dword of the step pair, low nibbles = even step, high nibbles = odd step
+          const uint32_t H = ((pp >> 1) ? r.q[2].y : r.q[2].x) >> (4 * (pp & 1));
+          bw.x |= (int)((H & 0x01010101u) << 4);
+          bw.y |= (int)(((H >> 1) & 0x01010101u) << 4);
+          bw.z |= (int)(((H >> 2) & 0x01010101u) << 4);
+          bw.w |= (int)(((H >> 3) & 0x01010101u) << 4);
+        }
         const i32x4 zero = {0, 0, 0, 0};
         const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(areg[pp], bw, zero, 0, 0, 0);
-        // both halves exact in f32: |D0| <= 64*15*16, |D1..3| <= 128*15*16
+        // both halves exact in f32: |D0| <= 64*31*16, |D1..3| <= 128*31*16
         const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
         const float V = __builtin_fmaf(hi, 65536.0f, lo);
         s1 = __builtin_fmaf(scf[pp] * sx[pp], V, s1);
@@ -451,18 +603,25 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
     };
     auto x_finish = [&](auto n_tiles) {
       constexpr int NT = decltype(n_tiles)::value;
-      // n_tiles tiles x (5 | 3) loads were issued behind the x requests
-      if (is_q6) {
-        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      } else {
-        if constexpr (NT == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr (NT == 3) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      }
+      // n_tiles x fmt_loads_per_tile loads were issued behind the x requests
+#define LGH_WAIT_BEHIND(LPT)                                                                      \
+  do {                                                                                           \
+    if constexpr (NT * (LPT) == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");             \
+    else if constexpr (NT * (LPT) == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        \
+    else if constexpr (NT * (LPT) == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");        \
+    else if constexpr (NT * (LPT) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");        \
+    else if constexpr (NT * (LPT) == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        \
+    else if constexpr (NT * (LPT) == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");          \
+    else if constexpr (NT * (LPT) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          \
+    else if constexpr (NT * (LPT) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          \
+    else if constexpr (NT * (LPT) == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          \
+    else if constexpr (NT * (LPT) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");          \
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                         \
+  } while (0)
+      if (is(F_Q6K) || is(F_Q80)) LGH_WAIT_BEHIND(5);
+      else if (is(F_Q5K)) LGH_WAIT_BEHIND(4);
+      else LGH_WAIT_BEHIND(3);
+#undef LGH_WAIT_BEHIND
       LGH_WSTAMP(4);
     };
 
@@ -572,16 +731,16 @@ size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
-template <int FMT>
+template <uint32_t MASK>
 static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
                          uint32_t geom2, uint32_t red_off) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel<FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((mvq_kernel<FMT>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
+  hipLaunchKernelGGL((mvq_kernel<MASK>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
   return hipGetLastError();
 }
 
@@ -589,15 +748,15 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
   const MvSeg& S0 = L.seg[0];
   const size_t lds = mvq_lds_bytes(threads / 64, S0.units, L.red_floats);
   if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0 || L.nseg < 1 || L.nseg > 3) return hipErrorInvalidValue;
-  int n4 = 0, n6 = 0;
+  uint32_t mask = 0;
   for (int i = 0; i < L.nseg; i++) {   // the launch-uniform geometry travels as preloaded scalars
     const MvSeg& Si = L.seg[i];
     if (Si.T != S0.T || Si.G != S0.G || Si.units != S0.units || Si.nblk != S0.nblk || Si.rows_per_wg != S0.rows_per_wg ||
         (i > 0 && Si.wg_begin >= 0xFFFFu))
       return hipErrorInvalidValue;
-    if (Si.type == kDevQ4K_T16) n4++;
-    else if (Si.type == kDevQ6K_T16) n6++;
-    else return hipErrorInvalidValue;
+    const int f = fmt_of_dev_type(Si.type);
+    if (f < 0) return hipErrorInvalidValue;
+    mask |= 1u << f;
   }
   const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
   if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return hipErrorInvalidValue;
@@ -605,9 +764,13 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
   const uint32_t geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
   const uint32_t geom2 = S0.nblk | Rg << 16;
   const uint32_t red_off = mvq_red_offset(threads / 64, S0.units);
-  if (n6 == 0) return mvq_go<0>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-  if (n4 == 0) return mvq_go<1>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-  return mvq_go<2>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+#define LGH_MVQ_CASE(M) case M: return mvq_go<M>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
+  switch (mask) {   // single formats and the two mixes of the "_M" quantisations (fused QKV: V in Q6_K)
+    LGH_MVQ_CASE(1u << F_Q4K); LGH_MVQ_CASE(1u << F_Q6K); LGH_MVQ_CASE(1u << F_Q5K); LGH_MVQ_CASE(1u << F_Q80); LGH_MVQ_CASE(1u << F_Q40);
+    LGH_MVQ_CASE((1u << F_Q4K) | (1u << F_Q6K)); LGH_MVQ_CASE((1u << F_Q5K) | (1u << F_Q6K));
+    default: return hipErrorInvalidValue;   // other mixes: the caller launches one format at a time
+  }
+#undef LGH_MVQ_CASE
 }
 
 }  // namespace lgh

@@ -37,8 +37,6 @@ def test_dequantize_bit_exact(gpu, pkg, orc, tname):
 def test_fused_vec_mat(gpu, pkg, orc, tname, k, n):
     """k covers one block, even and uneven k-slices (TinyLlama ffn 5632 = 22 blocks), 7 and 14 blocks per wave (the
     70B ffn width fills 143 KB of LDS with XQ records); n covers ragged tails."""
-    if k > 16384 and tname not in ("Q4_K", "Q6_K"):
-        pytest.skip("the VALU kernel (Q5_K / Q8_0 / Q4_0) stages x as f32 in LDS: k <= 16384; wider inputs are a next step")
     t, raw = _weights(pkg, tname, k, n)
     x = np.random.default_rng(k + n).standard_normal(k).astype(np.float32)
     want = orc.vec_mat_q(t, raw, x, n)
