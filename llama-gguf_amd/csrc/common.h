@@ -122,6 +122,7 @@ struct MvSeg {
   uint32_t max_seq;
   // optional: also leave the output vector as XQ records for an int8-MFMA consumer (store / residual / SwiGLU epilogues)
   uint8_t* xq_out;           // XQ image of `out` (n_rows must be a multiple of 16)
+  uint8_t* xq_out2;          // ... and of `out2` (MoE SwiGLU: the second expert's activation)
   const float* xq_nw;        // the consumer's RMSNorm weights: records hold out * xq_nw, and ...
   float* xq_ssq;             // ... xq_ssq[row / 16] = sum of out^2 over the chunk
 };

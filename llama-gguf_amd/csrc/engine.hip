@@ -302,10 +302,15 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
         S.xq_ssq = sp.xq_next == 2 ? qo->ssq : nullptr;
         qo->fresh = true;
         qo->tag = S.xq_nw;
+      } else if (sp.xq_next && qo && sp.epi == EPI_MOE_SWIGLU && W0.n % 16 == 0 && W0.n <= qo->k && plan.rows_per_wg % 16 == 0) {
+        XqBuf* q2 = sp.out2 ? xq_find(c, sp.out2) : nullptr;
+        S.xq_out = qo->xq;
+        qo->fresh = true; qo->tag = nullptr;
+        if (q2 && sp.npass > 2) { S.xq_out2 = q2->xq; q2->fresh = true; q2->tag = nullptr; }
       } else if (qo && sp.epi != EPI_ROPE_K && sp.epi != EPI_V_CACHE) {
         qo->fresh = false;
       }
-      if (sp.out2) xq_stale(c, sp.out2);
+      if (sp.out2 && !S.xq_out2) xq_stale(c, sp.out2);
     }
     S.head_dim = c->d.head_dim;
     S.max_seq = c->d.max_seq_len;
@@ -470,6 +475,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     }
     sp.epi = EPI_MOE_SWIGLU;
     sp.out = c->act; sp.out2 = c->act2;
+    sp.xq_next = mfma_type(Lw.down_exps.type) ? 1 : 0;
     if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
   }
   {

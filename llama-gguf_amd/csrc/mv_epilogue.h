@@ -105,7 +105,10 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
       for (int e = 0; 2 * e + 1 < S.npass; e++) {
         float g = rowval(2 * e, t), up = rowval(2 * e + 1, t);
         float* o = e == 0 ? S.out : S.out2;
-        o[row] = silu_f(g) * up;
+        const float a = silu_f(g) * up;
+        o[row] = a;
+        uint8_t* xo = e == 0 ? S.xq_out : S.xq_out2;   // each expert's activation feeds its own down projection
+        if (xo) xq_store_chunk(xo, row >> 4, a);
       }
       break;
     }
