@@ -236,6 +236,11 @@ int lgh_op_swiglu_vec_mat(int device, uint32_t ggml_type, const void* w_gate, co
 int lgh_bench_vec_mat(int device, uint32_t ggml_type, const void* w, const void* w2, size_t k, size_t n, int mode,
                       int iters, int copies, double* avg_us);
 
+/* Streaming-read probe: `iters` passes over a `bytes`-long device buffer with 16-byte non-temporal loads from every CU
+ * (the access pattern of the weight stream); gbps = bytes * iters / device time.  The practical HBM ceiling the decode
+ * roofline is also quoted against (bench.py: hbm_roofline.measured_read_peak_GBps). */
+int lgh_bench_hbm_read(int device, size_t bytes, int iters, double* gbps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,7 @@ int mv_symbol(const MvLaunch& L);
 hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
+hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st);   // streaming-read probe
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
 hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick

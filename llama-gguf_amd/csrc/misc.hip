@@ -226,4 +226,28 @@ hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, con
   return hipGetLastError();
 }
 
+// Streaming-read probe: every workgroup walks its share of the buffer with 16-byte loads, 16 in flight per lane; the
+// xor-reduction only keeps the loads alive.  NT selects non-temporal loads (the weight stream's policy).
+template <bool NT>
+__global__ void __launch_bounds__(512) hbm_read_kernel(const u32x4* __restrict__ buf, size_t n16, float* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * 512;
+  u32x4 acc = {0, 0, 0, 0};
+  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  for (; i + 15 * stride < n16; i += 16 * stride) {
+    u32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = NT ? __builtin_nontemporal_load(buf + i + j * stride) : buf[i + j * stride];
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc ^= v[j];
+  }
+  for (; i < n16; i += stride) acc ^= buf[i];
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[blockIdx.x & 4095] = 1.0f;   // never true for the 0x01 fill
+}
+
+hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st) {
+  if (nt) hipLaunchKernelGGL((hbm_read_kernel<true>), dim3(kNumCU * 2), dim3(512), 0, st, reinterpret_cast<const u32x4*>(buf), bytes / 16, sink);
+  else hipLaunchKernelGGL((hbm_read_kernel<false>), dim3(kNumCU * 2), dim3(512), 0, st, reinterpret_cast<const u32x4*>(buf), bytes / 16, sink);
+  return hipGetLastError();
+}
+
 }  // namespace lgh

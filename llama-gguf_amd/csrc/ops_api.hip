@@ -9,9 +9,10 @@
 
 using namespace lgh;
 
+#include <algorithm>
+
 #ifdef LGH_STAMPS
 namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); hipError_t mvq_spans(unsigned long long* host, int reset); }
-#include <algorithm>
 #include <cstdio>
 #endif
 
@@ -288,6 +289,36 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
     }
   }
 #endif
+  return LGH_OK;
+}
+
+int lgh_bench_hbm_read(int device, size_t bytes, int iters, double* gbps) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!gbps || iters <= 0 || bytes < (1u << 20)) return LGH_INVALID_ARGUMENT;
+  bytes &= ~(size_t)4095;
+  uint8_t* buf = nullptr;
+  float* sink = nullptr;
+  if (dev_alloc(t.c, (void**)&buf, bytes) || dev_alloc(t.c, (void**)&sink, 4096 * 4)) return LGH_ALLOCATION_FAILED;
+  if (hipMemsetAsync(buf, 1, bytes, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  double best = 0.0;
+  for (int nt = 0; nt < 2; nt++) {   // both cache policies; the better one is the ceiling
+    if (hbm_read_launch(buf, bytes, sink, nt, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;   // warm-up
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return LGH_OPERATION_FAILED;
+    (void)hipEventRecord(a, t.c->stream);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < iters && e == hipSuccess; i++) e = hbm_read_launch(buf, bytes, sink, nt, t.c->stream);
+    (void)hipEventRecord(b, t.c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (e != hipSuccess) return LGH_OPERATION_FAILED;
+    best = std::max(best, (double)bytes * iters / ((double)ms * 1e-3) / 1e9);
+  }
+  *gbps = best;
   return LGH_OK;
 }
 

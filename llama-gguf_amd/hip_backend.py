@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
-    "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat",
+    "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
@@ -108,6 +108,7 @@ def load_library() -> C.CDLL:
         "lgh_op_norm_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+        "lgh_bench_hbm_read": (C.c_int, [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -366,3 +367,10 @@ def bench_vec_mat(ggml_type: int, w: np.ndarray, k: int, n: int, mode: int = 0, 
     _chk(load_library().lgh_bench_vec_mat(device, ggml_type, w.ctypes.data, w2.ctypes.data if w2 is not None else None,
                                           k, n, mode, iters, copies, C.byref(us)), "bench_vec_mat")
     return us.value
+
+
+def bench_hbm_read(nbytes: int = 1 << 30, iters: int = 10, device: int = 0) -> float:
+    """Measured streaming-read rate of the device in GB/s (the practical ceiling next to the 8 TB/s spec peak)."""
+    out = C.c_double(0.0)
+    _chk(load_library().lgh_bench_hbm_read(device, nbytes, iters, C.byref(out)), "bench_hbm_read")
+    return float(out.value)
