@@ -65,6 +65,11 @@ def main():
 
     rl = bench["roofline"]
     kname = rl["kernel"]
+    if rl.get("traffic") is None:   # the bench line ran before this session's PMC table existed: fill it from the same session
+        for r in rows:
+            if r[0] == kname and r[1] > 0:
+                rl["traffic"], rl["traffic_source"] = int(r[5]), f"{tag}_pmc_traffic.csv"
+        (dst / f"{tag}_bench.json").write_text(json.dumps(bench) + "\n")
     with open(stats, newline="") as f:
         st = {short(r["Name"]): r for r in csv.DictReader(f)}
     lines = [f"# {tag}: measurement summary", "",
