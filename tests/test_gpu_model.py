@@ -211,3 +211,47 @@ def test_cpp_host_mirror(pkg, orc, tmp_path):
         assert int(head.split()[-1]) == orc.argmax_last(want) == orc.argmax_last(got)
         toks = [orc.argmax_last(want)]
     assert out[4] == "error-variant InvalidArgument"
+
+
+def test_full_size_llama3_8b_q4_k_m_matches_oracle(pkg, orc):
+    """BASELINE.json's headline configuration at FULL size (32 layers, hidden 4096, ffn 14336, vocab 128256, Q4_K_M mix
+    with its Q6_K matrices): logits of a short prompt and of three greedy steps against the CPU oracle (~0.3 s per token
+    there), greedy tokens identical where the oracle's top-1/top-2 gap exceeds the measured error; then a size-independent
+    property at the full decode length: 64 more device-fed greedy steps are deterministic run to run."""
+    cfg = pkg.make_config("llama-3-8b", max_seq_len=128)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    ref = orc.Model(cfg.as_dict())
+    eng = None
+    try:
+        for nm, t, ne, data in model.tensors():
+            ref.add_tensor(nm, t, ne, data)
+        ref.finalize()
+        eng = pkg.HipGpuInference.from_model(model, 128)
+        prompt = [i % cfg.vocab_size for i in (1, 128000, 77, 31999)]
+        for t in prompt[:-1]:
+            eng.prefill_token(t)
+        got, want = eng.forward(prompt[-1]), ref.forward(prompt)
+        for step in range(4):
+            err = float(np.abs(got - want).max())
+            assert err <= _tol(want), f"step {step}: max|dlogit| {err:.3e} > {_tol(want):.3e}"
+            srt = np.sort(want)
+            tok = orc.argmax_last(want)
+            if float(srt[-1] - srt[-2]) > 4 * err:
+                assert orc.argmax_last(got) == tok
+            if step < 3:
+                got, want = eng.forward(tok), ref.forward([tok])
+        pos = eng.position()
+        a = eng.decode_greedy(tok, 64).tolist()
+        eng.reset()
+        for t in prompt[:-1]:
+            eng.prefill_token(t)
+        tk = prompt[-1]
+        for _ in range(pos - len(prompt) + 1):   # replay the same 3 fed tokens
+            tk = orc.argmax_last(eng.forward(tk))
+        assert eng.position() == pos
+        b = eng.decode_greedy(tok, 64).tolist()
+        assert a == b and len(set(a)) > 1
+    finally:
+        ref.close()
+        if eng is not None:
+            eng.close()
