@@ -86,6 +86,7 @@ typedef struct lgh_model_desc {
 
 enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
+  LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8     /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
 };
 

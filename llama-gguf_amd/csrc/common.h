@@ -142,6 +142,12 @@ struct MvLaunch {
   MvSeg seg[3];
 };
 
+// chained int8-MFMA ops (one launch, grid barriers in between; matvec_mfma.hip)
+struct MvChainOp { uint32_t wbpack, geom, geom2, red_floats, lds_red_off, n_wg, pad0, pad1; };
+constexpr int kChainMaxOps = 4;
+constexpr int kChainSyncWords = 640;   // launch base, top, per-XCD counters and generations, error flag
+struct MvChainHost { MvLaunch op[kChainMaxOps]; MvChainOp geo[kChainMaxOps]; int nops; uint32_t mask, threads; size_t lds; };
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (defined in the .hip files)
 // ---------------------------------------------------------------------------------------------
@@ -160,6 +166,8 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st);   // streaming-read probe
+hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h);
+hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st);
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
 hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick

@@ -27,6 +27,9 @@ enum TokenMode { MODE_PREFILL = 0, MODE_FORWARD = 1, MODE_GREEDY = 2, MODE_COUNT
 // current contents; `tag` = the RMSNorm weights it was multiplied with (nullptr: none).
 struct XqBuf { const float* f32 = nullptr; uint8_t* xq = nullptr; float* ssq = nullptr; uint32_t k = 0; bool fresh = false; const float* tag = nullptr; };
 
+// one chained FFN launch (engine.hip: launch_ffn_chain): host copy of the descriptors + their device image
+struct ChainSlot { MvChainHost host; uint8_t* dev = nullptr; bool prepared = false, uploaded = false; };
+
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
 }  // namespace lgh
@@ -63,6 +66,9 @@ struct lgh_ctx {
   std::vector<lgh::ProfRec> prof;
   std::vector<void*> allocs;  // everything hipMalloc'ed by this context
   std::vector<lgh::XqBuf> xqs;
+  std::vector<lgh::ChainSlot> chains;          // [graph mode][layer]
+  std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
+  unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
 };
 
 // ---- helpers shared by engine.hip and ops_api.hip ----

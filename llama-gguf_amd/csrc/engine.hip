@@ -229,8 +229,10 @@ void xq_stale(lgh_ctx* c, const float* f32) {
 }
 
 static uint32_t g_launch_seq = 0;   // diagnostic builds: consecutive launches get consecutive span slots
-static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma) {
-  MvLaunch L;
+// Assembles the launch descriptor of one group of segments (and keeps the XQ bookkeeping: images this launch consumes are
+// converted here if their producer did not leave them; images it produces are marked fresh).
+static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma, MvLaunch& L,
+                          uint32_t& wg, uint32_t& threads, uint64_t& alg) {
   std::memset(&L, 0, sizeof(L));
   L.nseg = nseg;
   L.k = k;
@@ -240,8 +242,8 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
   L.dbg_slot = g_launch_seq++ & 63u;
-  uint32_t wg = 0, threads = 0, launch_rows = 0;
-  uint64_t alg = 0;
+  wg = 0; threads = 0; alg = 0;
+  uint32_t launch_rows = 0;
   uint32_t wave_cap = 16;
   for (int s = 0; s < nseg; s++) {
     launch_rows += specs[s].W[0]->n;
@@ -319,17 +321,67 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
     if (plan.red_floats > L.red_floats) L.red_floats = plan.red_floats;
   }
   alg += (uint64_t)k * 4 * (norm_w ? 2 : 1);
-  if (mfma) {
-    bool has[8] = {false, false, false, false, false, false, false, false};
-    for (int s = 0; s < nseg; s++) {
-      const int t = L.seg[s].type;
-      has[t == kDevQ4K_T16 ? 0 : t == kDevQ6K_T16 ? 1 : t == kDevQ5K_T16 ? 2 : t == kDevQ80_T16 ? 3 : 4] = true;
-    }
-    const int sym = has[2] ? LGH_SYM_MVQ_Q5K : (has[3] || has[4]) ? LGH_SYM_MVQ_Q80_Q40 : (has[0] && has[1]) ? LGH_SYM_MVQ_MIXED
-                    : has[1] ? LGH_SYM_MVQ_Q6K : LGH_SYM_MVQ_Q4K;
-    return run_k(c, cls, sym, alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
+  return LGH_OK;
+}
+
+static int mvq_symbol(const MvLaunch& L) {
+  bool has[8] = {false, false, false, false, false, false, false, false};
+  for (int s = 0; s < L.nseg; s++) {
+    const int t = L.seg[s].type;
+    has[t == kDevQ4K_T16 ? 0 : t == kDevQ6K_T16 ? 1 : t == kDevQ5K_T16 ? 2 : t == kDevQ80_T16 ? 3 : 4] = true;
   }
+  return has[2] ? LGH_SYM_MVQ_Q5K : (has[3] || has[4]) ? LGH_SYM_MVQ_Q80_Q40 : (has[0] && has[1]) ? LGH_SYM_MVQ_MIXED
+         : has[1] ? LGH_SYM_MVQ_Q6K : LGH_SYM_MVQ_Q4K;
+}
+
+static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma) {
+  MvLaunch L;
+  uint32_t wg, threads;
+  uint64_t alg;
+  int rc = build_mv_group(c, specs, nseg, norm_w, k, mfma, L, wg, threads, alg);
+  if (rc) return rc;
+  if (mfma) return run_k(c, cls, mvq_symbol(L), alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chained dense FFN block: wo (+residual) -> gate/up (SwiGLU) -> down (+residual) in ONE launch with grid barriers in
+// between (matvec_mfma.hip: mvq_chain_kernel).  The descriptors are static per (graph mode, layer): built at the first
+// enqueue, uploaded once — during a stream capture the upload is deferred until the capture has ended.
+// ------------------------------------------------------------------------------------------------
+static int launch_ffn_chain(lgh_ctx* c, int mode, uint32_t li, const SegSpec* specs, const float* const* norm_ws, const uint32_t* ks,
+                            const int* clss, int nops) {
+  MvLaunch Ls[kChainMaxOps];
+  uint32_t wgs[kChainMaxOps], ths[kChainMaxOps];
+  uint64_t alg = 0;
+  for (int i = 0; i < nops; i++) {
+    uint64_t a = 0;
+    int rc = build_mv_group(c, specs + i, 1, norm_ws[i], ks[i], true, Ls[i], wgs[i], ths[i], a);
+    if (rc) return rc;
+    alg += a;
+  }
+  ChainSlot& slot = c->chains[(size_t)mode * c->d.num_layers + li];
+  if (!slot.prepared) {
+    if (mvq_chain_prepare(Ls, wgs, ths, nops, &slot.host) != hipSuccess) return fail(c, LGH_UNSUPPORTED, "FFN chain: unsupported geometry");
+    slot.prepared = true;
+    slot.uploaded = false;
+  }
+  if (!slot.uploaded) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cs);
+    if (cs == hipStreamCaptureStatusNone) {
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(slot.dev, slot.host.op, sizeof(MvLaunch) * kChainMaxOps, hipMemcpyHostToDevice));
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(slot.dev + sizeof(MvLaunch) * kChainMaxOps, slot.host.geo, sizeof(MvChainOp) * kChainMaxOps, hipMemcpyHostToDevice));
+      slot.uploaded = true;
+    } else {
+      c->chain_pending.push_back(&slot);   // uploaded by capture_graph() right after hipStreamEndCapture
+    }
+  }
+  const MvLaunch* dev_ops = reinterpret_cast<const MvLaunch*>(slot.dev);
+  const MvChainOp* dev_geo = reinterpret_cast<const MvChainOp*>(slot.dev + sizeof(MvLaunch) * kChainMaxOps);
+  (void)clss;
+  return run_k(c, LGH_K_GATEUP, slot.host.mask == 1u ? LGH_SYM_MVQ_Q4K : LGH_SYM_MVQ_MIXED, alg,
+               [&] { return mvq_chain_launch(slot.host, dev_ops, dev_geo, c->chain_sync, c->stream); });
 }
 
 // Segments are independent (disjoint outputs), so a launch whose matrices live in different kernel families
@@ -384,7 +436,7 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
 // ------------------------------------------------------------------------------------------------
 // `next_nw` / `next_mfma`: the norm weights and kernel family of whatever consumes this layer's output (the next layer's
 // QKV, or the output projection)
-static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool next_mfma) {
+static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool next_mfma, int mode) {
   LayerW& Lw = c->layers[li];
   const lgh_model_desc& d = c->d;
   const uint32_t H = d.hidden_size;
@@ -433,6 +485,22 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   }
   // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
   const bool ffn_mfma = Lw.moe() ? mfma_type(Lw.gate_exps.type) : mfma_type(Lw.gate.type);
+  auto q46 = [](int t) { return t == kDevQ4K_T16 || t == kDevQ6K_T16; };
+  if ((d.flags & LGH_FLAG_CHAIN_FFN) && !c->profiling && !Lw.moe() && q46(Lw.wo.type) && q46(Lw.gate.type) && Lw.gate.type == Lw.up.type &&
+      q46(Lw.down.type) && !Lw.bo && c->chain_sync) {
+    // wo -> gate/up -> down in one launch (resident workgroups, grid barriers instead of kernel boundaries)
+    SegSpec sp[3];
+    sp[0].W[0] = &Lw.wo; sp[0].x[0] = c->attn_out; sp[0].epi = EPI_RESID; sp[0].out = c->hidden; sp[0].resid = c->hidden;
+    sp[0].xq_next = 2; sp[0].xq_next_nw = Lw.ffn_norm;
+    sp[1].npass = 2; sp[1].W[0] = &Lw.gate; sp[1].W[1] = &Lw.up; sp[1].x[0] = sp[1].x[1] = c->hidden; sp[1].epi = EPI_SWIGLU;
+    sp[1].out = c->act; sp[1].xq_next = 1;
+    sp[2].W[0] = &Lw.down; sp[2].x[0] = c->act; sp[2].epi = EPI_RESID; sp[2].out = c->hidden; sp[2].resid = c->hidden;
+    sp[2].xq_next = next_mfma ? 2 : 0; sp[2].xq_next_nw = next_nw;
+    const float* nws[3] = {nullptr, Lw.ffn_norm, nullptr};
+    const uint32_t ks[3] = {Lw.wo.k, H, Lw.down.k};
+    const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
+    return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3);
+  }
   if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
   if (c->profiling) {  // an EMPTY event bracket in mid-stream: what the measurement itself adds to every sample (at the
     // head of a token, on an idle stream, the same bracket reads differently from run to run)
@@ -519,7 +587,7 @@ static int enqueue_token(lgh_ctx* c, int mode) {
       next_nw = c->output_norm;
       next_mfma = mfma_type(c->output.type);
     }
-    if ((rc = layer_forward(c, li, next_nw, next_mfma))) return rc;
+    if ((rc = layer_forward(c, li, next_nw, next_mfma, mode))) return rc;
   }
   if (c->last && mode != MODE_PREFILL) {
     // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
@@ -538,8 +606,18 @@ static int ensure_graph(lgh_ctx* c, int mode) {
   if (c->graph[mode]) return LGH_OK;
   hipGraph_t g = nullptr;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  c->chain_pending.clear();
   int rc = enqueue_token(c, mode);
   hipError_t e = hipStreamEndCapture(c->stream, &g);
+  for (ChainSlot* slot : c->chain_pending) {   // descriptor images of the chained launches (static per mode and layer)
+    if (rc || e != hipSuccess || slot->uploaded) continue;
+    if (hipMemcpy(slot->dev, slot->host.op, sizeof(MvLaunch) * kChainMaxOps, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(slot->dev + sizeof(MvLaunch) * kChainMaxOps, slot->host.geo, sizeof(MvChainOp) * kChainMaxOps, hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(c, LGH_OPERATION_FAILED, "chain descriptor upload failed");
+    else
+      slot->uploaded = true;
+  }
+  c->chain_pending.clear();
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   size_t n_nodes = 0;
@@ -566,6 +644,14 @@ static int step(lgh_ctx* c, int mode) {
   c->pos += 1;
   c->stats.tokens_processed += 1;
   return LGH_OK;
+}
+
+// a chained launch whose grid barrier timed out raised this flag (bounded spins: the launch still ran to completion)
+static int check_chain(lgh_ctx* c) {
+  if (!c->chain_sync) return LGH_OK;
+  unsigned flag = 0;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->chain_sync + 576, 4, hipMemcpyDeviceToHost));
+  return flag ? fail(c, LGH_OPERATION_FAILED, "grid barrier of a chained launch timed out (code " + std::to_string(flag) + ")") : LGH_OK;
 }
 
 static int bind(const lgh_ctx* c) { return hipSetDevice(c->device) == hipSuccess ? LGH_OK : LGH_NOT_AVAILABLE; }
@@ -787,6 +873,18 @@ int lgh_finalize(lgh_ctx* c) {
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
   }
+  if (d.flags & LGH_FLAG_CHAIN_FFN) {
+    // the chained launch is kNumCU workgroups that wait for each other: every one of them must be resident, i.e. the
+    // device must really have that many CUs to give (otherwise the flag is ignored)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= kNumCU) {
+      c->chains.assign((size_t)MODE_COUNT * d.num_layers, ChainSlot{});
+      for (auto& slot : c->chains)   // device images allocated here, never during a graph capture
+        if ((rc = dev_alloc(c, (void**)&slot.dev, sizeof(MvLaunch) * kChainMaxOps + sizeof(MvChainOp) * kChainMaxOps))) return rc;
+      if ((rc = dev_alloc(c, (void**)&c->chain_sync, kChainSyncWords * 4))) return rc;
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->chain_sync, 0, kChainSyncWords * 4, c->stream));
+    }
+  }
   // XQ images of the vectors that feed quantized mat-vecs (allocated here, never during a graph capture)
   if (!xq_get(c, c->hidden, d.hidden_size) || !xq_get(c, c->attn_out, d.num_heads * d.head_dim) || !xq_get(c, c->act, (uint32_t)ffn) ||
       !xq_get(c, c->act2, (uint32_t)ffn))
@@ -897,7 +995,7 @@ int lgh_decode_greedy(lgh_ctx* c, uint32_t first_token, size_t n_steps, uint32_t
     if ((rc = step(c, MODE_GREEDY))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(tokens_out, c->tok_log + pos0, n_steps * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return LGH_OK;
+  return check_chain(c);
 }
 
 const char* lgh_last_error(const lgh_ctx* c) { return c ? c->err.c_str() : "null context"; }

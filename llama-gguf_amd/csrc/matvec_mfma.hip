@@ -22,6 +22,7 @@
 // eight bytes per step:  N0, N1 with byte t = w[t] | w[t+4] << 4  (w = elements 0-7 / 8-15 of the chunk), so B-operand
 // dwords are N0 & 0x0F.., N0 >> 4 & 0x0F.., N1 & 0x0F.., N1 >> 4 & 0x0F.. and every lane loads only its own nibbles:
 //   [0, 1024) lane-major 16 B: N0,N1 of steps 0,1    [1024, 2048) steps 2,3    [2048, 2304) the 16 native 16-byte headers
+#include <algorithm>
 #include <type_traits>
 
 #include "device_utils.h"
@@ -340,15 +341,15 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 // geom  = T | G << 8 | nbw << 16 | do_norm << 31         geom2 = nblk | Rg << 16        wbpack = wg_begin[1] | wg_begin[2] << 16
 // offA/B/C = byte strides of a workgroup / a row-group / a k-slice inside one pass's tile array
 // MASK: the formats (1 << F_*) the instantiation handles; with more than one the segment's type decides at run time
-template <uint32_t MASK>
-__global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
-                                                          uint32_t lds_red_off, const MvLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+// COH: the op runs inside a chain (mvq_chain_kernel): its inputs may have been written earlier in the same launch by
+// workgroups on other XCDs, and its outputs are read later in the same launch — agent-scope loads / write-through stores.
+template <uint32_t MASK, bool COH>
+__device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
+                                         uint32_t lds_red_off, const MvLaunch& L, uint8_t* smem8) {
   // the position word (RoPE epilogues): its scalar load goes out with the very first kernarg loads, no wait here
   const int* L_pos = L.pos;
   uint32_t pos_now;
   asm volatile("s_load_dword %0, %1, 0x0" : "=s"(pos_now) : "s"(L_pos) : "memory");
-  const uint32_t bid = blockIdx.x;
   const int s = (int)(bid >= (wbpack & 0xFFFFu)) + (int)(bid >= (wbpack >> 16));   // 0xFFFF = no such segment
   const MvSeg& S = L.seg[s];
   const uint32_t S_nrows = S.n_rows, S_wgb = S.wg_begin, S_head_dim = S.head_dim;
@@ -428,10 +429,10 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   if (nrm && wave == 0) {
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (lane + 64 * j < L_n_ssq) ssp[j] = L_ssq_part[lane + 64 * j];
+      if (lane + 64 * j < L_n_ssq) ssp[j] = coh_load<COH>(L_ssq_part + lane + 64 * j);
   }
   MvEpiPre epi_pre = {0.0f, 0.0f, false};
-  mv_epilogue_prefetch_resid(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
+  mv_epilogue_prefetch_resid<COH>(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pos_now));   // long since there: the kernarg batch above was waited for
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
@@ -596,9 +597,14 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
         const uint8_t* src = xg + b * kXqRecord;
         const uint32_t dst = xrec_lds + b * kXqRecord;
         uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                     "s_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
+        if (COH)   // records written earlier in this launch by another XCD: agent-scope (sc1) loads
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_add_u32 m0, m0, 0x400\n\t"
+                       "s_nop 0\n\tglobal_load_lds_dword %2, off sc1\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
+        else
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\t"
+                       "s_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
       }
     };
     auto x_finish = [&](auto n_tiles) {
@@ -682,7 +688,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   }
   if (nrm && wave == 0) {   // the producer's partial sums of x^2 -> ssq[0]; the other waves contribute nothing
     float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
-    for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += L_ssq_part[i];
+    for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += coh_load<COH>(L_ssq_part + i);
     ss = wave_sum_to_lane63(ss);
     if (lane == 63) ssq[0] = ss;
   } else if (nrm && lane == 0) {
@@ -690,10 +696,74 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue(L, S, wg, red, ssq, S_T, epi_pre);
+  mv_epilogue<COH>(L, S, wg, red, ssq, S_T, epi_pre);
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);
+}
+
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
+                                                          uint32_t lds_red_off, const MvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  mvq_body<MASK, false>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Chained ops: several dependent mat-vecs (wo -> gate/up -> down) in ONE launch, the workgroups staying resident, with
+// a grid barrier between ops instead of a kernel boundary (measured: 2.6 us per XCD-hierarchical barrier with hand-off
+// vs ~4.7 us per graph node; tools/probes/grid_barrier_probe.hip).  MEASURED on Llama-3-8B: 553 tokens/s chained vs 604
+// launch-per-op — the hand-off (write-through stores drained before the barrier, agent-scope loads of the XQ records that
+// every workgroup needs, which therefore miss the XCD's L2) costs more than the kernel boundary it replaces; an L2
+// invalidate (buffer_inv sc1) after the barrier instead of sc1 loads was far worse (374).  The chain only pays once the
+// NEXT op's weight tiles are requested before the barrier; kept behind LGH_FLAG_CHAIN_FFN, bit-identical to the default.  Every CU holds exactly one workgroup (the launch is
+// kNumCU workgroups and each needs more than half a CU's registers), so all of them are resident and the barrier cannot
+// deadlock; its spins are bounded anyway and a timeout raises a flag the host checks.
+//   sync words: [0] launch base (barriers completed by earlier launches)  [32] top  [64 + 32x] count of XCD x
+//               [320 + 32x] generation of XCD x   [576] error
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned kChainSpinLimit = 1u << 22;
+
+__device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void chain_barrier(unsigned* sync, unsigned round, unsigned n_wg_launch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached the coherence point
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned x = blockIdx.x & 7u, per = (n_wg_launch + 7u - x) >> 3;   // workgroups with blockIdx % 8 == x
+    const unsigned old = __hip_atomic_fetch_add(&sync[64 + 32 * x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    if (old + 1 == (round + 1) * per) {   // last arrival of this XCD group: meet the other groups, then release the group
+      __hip_atomic_fetch_add(&sync[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned groups = n_wg_launch < 8u ? n_wg_launch : 8u;
+      while (chain_ld(&sync[32]) < (round + 1) * groups) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kChainSpinLimit) { sync[576] = 1; break; }
+      }
+      __hip_atomic_store(&sync[320 + 32 * x], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while (chain_ld(&sync[320 + 32 * x]) < round + 1) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kChainSpinLimit) { sync[576] = 2; break; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kWaves * 64) mvq_chain_kernel(const MvLaunch* __restrict__ ops, const MvChainOp* __restrict__ geo,
+                                                                int nops, unsigned* sync) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  const unsigned base = chain_ld(&sync[0]);   // same value in every workgroup: the previous launch has completed
+  for (int i = 0; i < nops; i++) {
+    const MvChainOp g = geo[i];
+    if (blockIdx.x < g.n_wg) mvq_body<MASK, true>(blockIdx.x, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8);
+    if (i + 1 < nops) chain_barrier(sync, base + (unsigned)i, gridDim.x);
+  }
+  // (no barrier after the last op: the kernel boundary orders it.)  Workgroup 0 has left the last barrier, so every
+  // workgroup has read `base`: advance it for the next launch.
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&sync[0], base + (unsigned)(nops - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -744,26 +814,39 @@ static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, siz
   return hipGetLastError();
 }
 
-hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+// launch-uniform geometry of one op, packed for the kernel; returns the format mask (0 = not launchable)
+static uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out) {
   const MvSeg& S0 = L.seg[0];
   const size_t lds = mvq_lds_bytes(threads / 64, S0.units, L.red_floats);
-  if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0 || L.nseg < 1 || L.nseg > 3) return hipErrorInvalidValue;
+  if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0 || L.nseg < 1 || L.nseg > 3) return 0;
   uint32_t mask = 0;
-  for (int i = 0; i < L.nseg; i++) {   // the launch-uniform geometry travels as preloaded scalars
+  for (int i = 0; i < L.nseg; i++) {   // the launch-uniform geometry travels as scalars
     const MvSeg& Si = L.seg[i];
     if (Si.T != S0.T || Si.G != S0.G || Si.units != S0.units || Si.nblk != S0.nblk || Si.rows_per_wg != S0.rows_per_wg ||
         (i > 0 && Si.wg_begin >= 0xFFFFu))
-      return hipErrorInvalidValue;
+      return 0;
     const int f = fmt_of_dev_type(Si.type);
-    if (f < 0) return hipErrorInvalidValue;
+    if (f < 0) return 0;
     mask |= 1u << f;
   }
   const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
-  if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return hipErrorInvalidValue;
-  const uint32_t wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
-  const uint32_t geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
-  const uint32_t geom2 = S0.nblk | Rg << 16;
-  const uint32_t red_off = mvq_red_offset(threads / 64, S0.units);
+  if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return 0;
+  g->wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
+  g->geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
+  g->geom2 = S0.nblk | Rg << 16;
+  g->red_floats = L.red_floats;
+  g->lds_red_off = mvq_red_offset(threads / 64, S0.units);
+  g->n_wg = n_wg;
+  g->pad0 = g->pad1 = 0;
+  *lds_out = lds;
+  return mask;
+}
+
+hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+  MvChainOp g;
+  size_t lds = 0;
+  const uint32_t mask = mvq_pack(L, n_wg, threads, &g, &lds);
+  const uint32_t wbpack = g.wbpack, geom = g.geom, geom2 = g.geom2, red_off = g.lds_red_off;
 #define LGH_MVQ_CASE(M) case M: return mvq_go<M>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
   switch (mask) {   // single formats and the two mixes of the "_M" quantisations (fused QKV: V in Q6_K)
     LGH_MVQ_CASE(1u << F_Q4K); LGH_MVQ_CASE(1u << F_Q6K); LGH_MVQ_CASE(1u << F_Q5K); LGH_MVQ_CASE(1u << F_Q80); LGH_MVQ_CASE(1u << F_Q40);
@@ -771,6 +854,47 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
     default: return hipErrorInvalidValue;   // other mixes: the caller launches one format at a time
   }
 #undef LGH_MVQ_CASE
+}
+
+// ---- chains
+hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h) {
+  if (nops < 2 || nops > kChainMaxOps) return hipErrorInvalidValue;
+  h->nops = nops;
+  h->mask = 0;
+  h->lds = 0;
+  h->threads = 0;
+  for (int i = 0; i < nops; i++) {
+    size_t lds = 0;
+    const uint32_t m = mvq_pack(Ls[i], n_wg[i], threads[i], &h->geo[i], &lds);
+    if (!m || n_wg[i] > (uint32_t)kNumCU) return hipErrorInvalidValue;
+    h->op[i] = Ls[i];
+    h->mask |= m;
+    h->lds = std::max(h->lds, lds);
+    h->threads = std::max(h->threads, threads[i]);
+  }
+  // instantiated chains: Q4_K, and Q4_K + Q6_K (the FFN of the Q4_K_M mix)
+  if (h->mask != (1u << F_Q4K) && h->mask != ((1u << F_Q4K) | (1u << F_Q6K)) && h->mask != (1u << F_Q6K)) return hipErrorInvalidValue;
+  for (int i = 0; i < nops; i++)
+    if (threads[i] != h->threads) return hipErrorInvalidValue;   // one launch geometry for all ops
+  return hipSuccess;
+}
+
+template <uint32_t MASK>
+static hipError_t chain_go(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_chain_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((mvq_chain_kernel<MASK>), dim3(kNumCU), dim3(h.threads), h.lds, st, dev_ops, dev_geo, h.nops, sync);
+  return hipGetLastError();
+}
+
+hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st) {
+  if (h.mask == (1u << F_Q4K)) return chain_go<(1u << F_Q4K)>(h, dev_ops, dev_geo, sync, st);
+  if (h.mask == (1u << F_Q6K)) return chain_go<(1u << F_Q6K)>(h, dev_ops, dev_geo, sync, st);
+  return chain_go<((1u << F_Q4K) | (1u << F_Q6K))>(h, dev_ops, dev_geo, sync, st);
 }
 
 }  // namespace lgh

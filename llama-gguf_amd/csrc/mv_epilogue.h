@@ -15,12 +15,13 @@ struct MvEpiPre { float a, b; bool valid; };
 
 // The residual element: issued first thing (one load, older than everything else in the wave's queue).  `epi` and
 // `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
+template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, const float* xq_nw, uint32_t n_rows, uint32_t wg,
                                                            uint32_t rows_per_wg, MvEpiPre& pre) {
   if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
     const uint32_t t = threadIdx.x, row = wg * rows_per_wg + t;
     if (t < rows_per_wg && row < n_rows) {
-      pre.a = resid[row];
+      pre.a = coh_load<COH>(resid + row);   // the residual stream may have been written earlier in this very launch
       pre.b = xq_nw ? xq_nw[row] : 1.0f;   // the next consumer's norm weight, for the XQ image of the output
       pre.valid = true;
     }
@@ -44,6 +45,7 @@ __device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos,
 
 // Per-row epilogue, one thread per row (or per row pair for RoPE)
 // `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
+template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
                                             const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false}) {
   const uint32_t t = threadIdx.x;
@@ -87,12 +89,12 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   float outv = 0.0f;        // the value written to out[row] by the epilogues that can also leave an XQ image
   bool has_out = false;
   switch (S.epi) {
-    case EPI_STORE: outv = v0; S.out[row] = outv; has_out = true; break;
-    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : S.resid[row]); S.out[row] = outv; has_out = true; break;
+    case EPI_STORE: outv = v0; coh_store<COH>(S.out + row, outv); has_out = true; break;
+    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : coh_load<COH>(S.resid + row)); coh_store<COH>(S.out + row, outv); has_out = true; break;
     case EPI_SWIGLU: {
       float up = rowval(1, t);
       outv = silu_f(v0) * up;
-      S.out[row] = outv;
+      coh_store<COH>(S.out + row, outv);
       has_out = true;
       break;
     }
@@ -129,7 +131,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   if (xq && has_out) {
     const float* nw = S.xq_nw;
     const float w = !nw ? 1.0f : (pre.valid && (S.epi == EPI_RESID || S.epi == EPI_MOE_DOWN)) ? pre.b : nw[row];
-    xq_store_chunk(xq, row >> 4, outv * w, S.xq_ssq, outv);
+    xq_store_chunk<COH>(xq, row >> 4, outv * w, S.xq_ssq, outv);
   }
 }
 

@@ -39,6 +39,7 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
              "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>")
 FLAG_NO_GRAPH = 1
+FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
 
 class BackendError(RuntimeError):
@@ -158,6 +159,8 @@ class HipGpuInference:
         d.device_id = device
         lb, le = (0, cfg.num_layers) if layer_range is None else (layer_range[0], layer_range[1])
         d.layer_begin, d.layer_end = lb, le
+        if os.environ.get("LGH_CHAIN_FFN", "") not in ("", "0"):
+            flags |= FLAG_CHAIN_FFN
         d.flags = flags | ((attn_splits & 0xFF) << 8)
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size

@@ -255,3 +255,25 @@ def test_full_size_llama3_8b_q4_k_m_matches_oracle(pkg, orc):
         ref.close()
         if eng is not None:
             eng.close()
+
+
+@pytest.mark.parametrize("name,mix", [("test-dense", "Q4_K_M"), ("test-dense-d128", "Q4_K_M"), ("test-dense", "Q6_K")])
+def test_chained_ffn_launch_matches_separate_launches(pkg, orc, name, mix):
+    """LGH_FLAG_CHAIN_FFN (wo -> gate/up -> down in one launch, grid barriers in between) must give exactly the logits of
+    the launch-per-op path: same kernels, same arithmetic, only the boundaries differ."""
+    cfg = pkg.make_config(name, max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix=mix)
+    a = pkg.HipGpuInference.from_model(model, 64)
+    b = pkg.HipGpuInference.from_model(model, 64, flags=pkg.hip_backend.FLAG_CHAIN_FFN)
+    try:
+        toks = [5, 900, 31, 7, 7, 123]
+        for t in toks[:-1]:
+            a.prefill_token(t)
+            b.prefill_token(t)
+        la, lb = a.forward(toks[-1]), b.forward(toks[-1])
+        assert np.array_equal(la, lb)
+        ta, tb = a.decode_greedy(3, 24).tolist(), b.decode_greedy(3, 24).tolist()
+        assert ta == tb
+    finally:
+        a.close()
+        b.close()
