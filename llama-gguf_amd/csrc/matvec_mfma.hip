@@ -715,8 +715,10 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint3
 // vs ~4.7 us per graph node; tools/probes/grid_barrier_probe.hip).  MEASURED on Llama-3-8B: 553 tokens/s chained vs 604
 // launch-per-op — the hand-off (write-through stores drained before the barrier, agent-scope loads of the XQ records that
 // every workgroup needs, which therefore miss the XCD's L2) costs more than the kernel boundary it replaces; an L2
-// invalidate (buffer_inv sc1) after the barrier instead of sc1 loads was far worse (374).  The chain only pays once the
-// NEXT op's weight tiles are requested before the barrier; kept behind LGH_FLAG_CHAIN_FFN, bit-identical to the default.  Every CU holds exactly one workgroup (the launch is
+// invalidate (buffer_inv sc1) after the barrier instead of sc1 loads was far worse (374).  Touching the next op's
+// first weight tiles into L2 before the barrier (LDS-DMA loads, stores drained first) made it slower still (502): the burst
+// competes with the barrier's own traffic and with the agent-scope x loads behind it.  Kept behind LGH_FLAG_CHAIN_FFN,
+// bit-identical to the default, as the starting point for a design whose hand-off is cheaper than a kernel boundary.  Every CU holds exactly one workgroup (the launch is
 // kNumCU workgroups and each needs more than half a CU's registers), so all of them are resident and the barrier cannot
 // deadlock; its spins are bounded anyway and a timeout raises a flag the host checks.
 //   sync words: [0] launch base (barriers completed by earlier launches)  [32] top  [64 + 32x] count of XCD x
@@ -726,8 +728,8 @@ constexpr unsigned kChainSpinLimit = 1u << 22;
 
 __device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// (the caller has drained its write-through stores)
 __device__ __forceinline__ void chain_barrier(unsigned* sync, unsigned round, unsigned n_wg_launch) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached the coherence point
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned x = blockIdx.x & 7u, per = (n_wg_launch + 7u - x) >> 3;   // workgroups with blockIdx % 8 == x
@@ -759,7 +761,10 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_chain_kernel(const MvLaunch* 
   for (int i = 0; i < nops; i++) {
     const MvChainOp g = geo[i];
     if (blockIdx.x < g.n_wg) mvq_body<MASK, true>(blockIdx.x, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8);
-    if (i + 1 < nops) chain_barrier(sync, base + (unsigned)i, gridDim.x);
+    if (i + 1 < nops) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached the coherence point
+      chain_barrier(sync, base + (unsigned)i, gridDim.x);
+    }
   }
   // (no barrier after the last op: the kernel boundary orders it.)  Workgroup 0 has left the last barrier, so every
   // workgroup has read `base`: advance it for the next launch.
