@@ -45,6 +45,37 @@ def committed_traffic(kernel):
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 
 
+def roofline_from_stats(st, P, step_us):
+    """`roofline` object for the kernel with the largest share of device time, from an eager profiled pass of P steps.
+
+    A hipEvent pair around ONE launch also times the bracket itself (event packets on the queue).  That fixed cost is
+    measured live with empty brackets in mid-stream and removed: `kernel_only_us`.  rocprofv3 --kernel-trace reports
+    back-to-back graph nodes with start(i+1) == end(i), i.e. each kernel's duration INCLUDES its dispatch gap; the same
+    figure is derived here from the timed graph replay: gap = (replayed step time - sum of kernel-only times) / graph
+    nodes.  `avg_launch_us` = kernel_only + gap is the number that must agree with the rocprofv3 average committed under
+    profiles/ and the one the roofline fraction is computed from.  (step_us None: no gap — pipeline stages, where the
+    step also contains the hops.)"""
+    syms = st["symbols"]
+    dom = max(syms, key=lambda s: syms[s]["time_us"])
+    d = syms[dom]
+    bracket_us = st["event_bracket_us"]
+    n_launch = sum(v["launches"] for v in syms.values()) / P
+    kernel_sum_us = sum(max(v["time_us"] - bracket_us * v["launches"], 0.0) for v in syms.values()) / P
+    gap_us = 0.0 if step_us is None else max(step_us - kernel_sum_us, 0.0) / max(n_launch, 1.0)
+    raw_us = d["time_us"] / d["launches"]
+    kernel_only_us = max(raw_us - bracket_us, 1e-3)
+    avg_us = kernel_only_us + gap_us
+    bytes_per_launch = d["alg_bytes"] / d["launches"]
+    achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    traffic, traffic_src = committed_traffic(dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "launches_per_step": d["launches"] / P, "avg_launch_us": round(avg_us, 3),
+            "kernel_only_us": round(kernel_only_us, 3), "dispatch_gap_us": round(gap_us, 3),
+            "avg_launch_us_with_event_bracket": round(raw_us, 3), "event_bracket_us": round(bracket_us, 3),
+            "alg_bytes_per_launch": int(bytes_per_launch)}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,31 +179,7 @@ def run_single(args, pkg):
         eng.set_profiling(False)
         st = eng.stats()
         syms = st["symbols"]
-        dom = max(syms, key=lambda s: syms[s]["time_us"])
-        d = syms[dom]
-        # A hipEvent pair around ONE launch also times the bracket itself (event packets on the queue).  That fixed cost
-        # is measured live with empty brackets in mid-stream and removed: `kernel_only_us`.  rocprofv3 --kernel-trace
-        # reports back-to-back graph nodes with start(i+1) == end(i), i.e. each kernel's duration INCLUDES its dispatch
-        # gap; the same figure is derived here from the timed graph replay: gap = (replayed step time - sum of
-        # kernel-only times) / graph nodes.  `avg_launch_us` = kernel_only + gap is the number that must agree with the
-        # rocprofv3 average committed under profiles/ and the one the roofline fraction is computed from.
-        bracket_us = st["event_bracket_us"]
-        step_us = 1e6 * elapsed / K
-        n_launch = sum(v["launches"] for v in syms.values()) / P
-        kernel_sum_us = sum(max(v["time_us"] - bracket_us * v["launches"], 0.0) for v in syms.values()) / P
-        gap_us = max(step_us - kernel_sum_us, 0.0) / max(n_launch, 1.0)
-        raw_us = d["time_us"] / d["launches"]
-        kernel_only_us = max(raw_us - bracket_us, 1e-3)
-        avg_us = kernel_only_us + gap_us
-        bytes_per_launch = d["alg_bytes"] / d["launches"]
-        achieved = bytes_per_launch / (avg_us * 1e-6) / 1e9
-        traffic, traffic_src = committed_traffic(dom)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "launches_per_step": d["launches"] / P, "avg_launch_us": round(avg_us, 3),
-                    "kernel_only_us": round(kernel_only_us, 3), "dispatch_gap_us": round(gap_us, 3),
-                    "avg_launch_us_with_event_bracket": round(raw_us, 3), "event_bracket_us": round(bracket_us, 3),
-                    "alg_bytes_per_launch": int(bytes_per_launch)}
+        roofline = roofline_from_stats(st, P, 1e6 * elapsed / K)
         tot = sum(v["time_us"] for v in syms.values())
         kernels = {s: {"launches_per_step": v["launches"] / P, "avg_us": round(v["time_us"] / v["launches"], 3),
                        "share": round(v["time_us"] / tot, 4),
@@ -254,6 +261,18 @@ def run_pipeline(args, pkg):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     kv1 = eng.position()
+    roofline = None
+    P = min(args.profile_steps, 8)
+    if P > 0:   # eager pass with a hipEvent pair around every launch; every rank takes part, rank 0 reports its stage
+        eng.set_profiling(True)
+        for _ in range(P):
+            tok = dec.step(tok)
+        eng.set_profiling(False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            roofline = roofline_from_stats(eng.stats(), P, None)
+            roofline["note"] = f"stage 0 of {world} (layers {lo}..{hi - 1}); kernel-only time, no dispatch gap added"
     if rank == 0:
         tok_s = K / elapsed
         step_bytes = model.step_alg_bytes(int(round((kv0 + 1 + kv1) / 2)))
@@ -267,7 +286,7 @@ def run_pipeline(args, pkg):
                        "prompt_tokens": args.prompt},
             "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
                              "peak_GBps_one_gpu": HBM_PEAK_GBPS, "frac_of_one_gpu": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": None,
         }))
     eng.close()
     dist.destroy_process_group()
