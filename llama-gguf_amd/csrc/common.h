@@ -180,7 +180,7 @@ hipError_t repack_launch(int src_type, const uint8_t* raw, uint8_t* dst, const u
 hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t n_elems, hipStream_t st);
 // dequantize row `*token` of a [vocab][hidden] table in its NATIVE GGUF layout into dst (embedding lookup)
 hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,
-                        hipStream_t st);
+                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st);
 
 // misc kernels
 hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st);

@@ -7,6 +7,7 @@
 // and the one row is dequantized on device — and (b) GGUF types without a fused mat-vec, which the
 // reference also expands to f32 at upload (src/backend/cuda/dequant_weights.rs:211-231).
 #include "device_utils.h"
+#include "xq.h"
 
 namespace lgh {
 
@@ -149,7 +150,8 @@ hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t
 // Thread 0 of block 0 also opens the token: state[POS] = state[NEXT]++ (every later kernel of this
 // token reads state[POS]; stream order makes the store visible).
 __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __restrict__ table, const int* token,
-                                                    float* __restrict__ dst, uint32_t hidden, int* state) {
+                                                    float* __restrict__ dst, uint32_t hidden, int* state,
+                                                    uint8_t* __restrict__ xq, const float* __restrict__ xq_nw, float* __restrict__ xq_ssq) {
   if (state && blockIdx.x == 0 && threadIdx.x == 0) {
     int p = state[ST_NEXT];
     state[ST_POS] = p;
@@ -157,14 +159,19 @@ __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __r
   }
   const uint64_t row = (uint64_t)(uint32_t)*token;
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < hidden) dst[i] = deq_any(type, table, row * hidden + i);
+  if (i < hidden) {
+    const float v = deq_any(type, table, row * hidden + i);
+    dst[i] = v;
+    // the first layer's QKV is an int8-MFMA consumer: leave its input as XQ records too (hidden % 256 == 0, host-checked)
+    if (xq) xq_store_chunk(xq, i >> 4, xq_nw ? v * xq_nw[i] : v, xq_ssq, v);
+  }
 }
 
 hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,
-                        hipStream_t st) {
-  if (!blk_elems(src_type)) return hipErrorInvalidValue;
+                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st) {
+  if (!blk_elems(src_type) || (xq && hidden % 256)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, src_type, table, token, dst, hidden,
-                     state);
+                     state, xq, xq_nw, xq_ssq);
   return hipGetLastError();
 }
 

@@ -566,15 +566,24 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
 static int enqueue_token(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   int rc;
+  for (auto& q : c->xqs) q.fresh = false;   // the residual stream is (re)written in f32 now (embedding / previous stage)
   if (c->first) {
+    // the embedding row, and — when the first layer's QKV runs on the matrix cores — its XQ image with that layer's norm weights
+    XqBuf* qh = nullptr;
+    const float* nw0 = nullptr;
+    if (c->l0 < c->l1 && mfma_type(c->layers[c->l0].wq.type) && d.hidden_size % 256 == 0) {
+      qh = xq_get(c, c->hidden, d.hidden_size);
+      nw0 = c->layers[c->l0].attn_norm;
+    }
     if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
-           return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, c->stream);
+           return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state,
+                               qh ? qh->xq : nullptr, nw0, qh ? qh->ssq : nullptr, c->stream);
          })))
       return rc;
+    if (qh) { qh->fresh = true; qh->tag = nw0; }
   } else {
     if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
   }
-  for (auto& q : c->xqs) q.fresh = false;   // the residual stream was just (re)written in f32 (embedding / previous stage)
   for (uint32_t li = c->l0; li < c->l1; li++) {
     // who consumes this layer's output: the next layer's QKV (attn_norm), the output projection (output_norm), or — at a
     // pipeline-stage boundary and at the end of a prefill step — nobody on this device
