@@ -237,6 +237,23 @@ int lgh_op_swiglu_vec_mat(int device, uint32_t ggml_type, const void* w_gate, co
 int lgh_bench_vec_mat(int device, uint32_t ggml_type, const void* w, const void* w2, size_t k, size_t n, int mode,
                       int iters, int copies, double* avg_us);
 
+/* ---- GGUF -> HBM direct loader: replaces GgufReader + ModelLoader::parse_config + from_model for this engine
+ * (src/gguf/reader.rs:49-104, src/model/loader.rs:62-170, src/backend/cuda/dequant_weights.rs:244-505).  The file is mapped
+ * and every tensor the engine knows is uploaded straight from the mapping in native GGUF layout. ---- */
+typedef struct lgh_gguf_info {
+  uint32_t version;                  /* GGUF version (1..3) */
+  uint32_t alignment;                /* general.alignment (default 32) */
+  uint64_t n_tensors, n_kv;
+  uint64_t data_offset, file_bytes;
+  char architecture[64];             /* general.architecture */
+  lgh_model_desc desc;               /* what ModelLoader::parse_config reads from the `{arch}.*` keys; max_seq_len = context_length */
+} lgh_gguf_info;
+/* Parses the header only (no GPU needed).  `err` (optional) receives a message on failure. */
+int lgh_gguf_inspect(const char* path, lgh_gguf_info* out, char* err, size_t errlen);
+/* create + upload + finalize from a GGUF file.  max_seq_len 0 = the file's context_length; layer_begin/end 0,0 = all. */
+int lgh_load_gguf(const char* path, uint32_t max_seq_len, int device, uint32_t flags, uint32_t layer_begin, uint32_t layer_end,
+                  lgh_ctx** out, char* err, size_t errlen);
+
 /* Streaming-read probe: `iters` passes over a `bytes`-long device buffer with 16-byte non-temporal loads from every CU
  * (the access pattern of the weight stream); gbps = bytes * iters / device time.  The practical HBM ceiling the decode
  * roofline is also quoted against (bench.py: hbm_roofline.measured_read_peak_GBps). */

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
-    "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read",
+    "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
@@ -62,6 +62,11 @@ class ModelDesc(C.Structure):
                 + [(n, C.c_float) for n in ("norm_eps", "rope_freq_base", "rope_freq_scale")]
                 + [("device_id", C.c_int32), ("layer_begin", C.c_uint32), ("layer_end", C.c_uint32),
                    ("flags", C.c_uint32)])
+
+
+class GgufInfo(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("alignment", C.c_uint32), ("n_tensors", C.c_uint64), ("n_kv", C.c_uint64),
+                ("data_offset", C.c_uint64), ("file_bytes", C.c_uint64), ("architecture", C.c_char * 64), ("desc", ModelDesc)]
 
 
 class Stats(C.Structure):
@@ -110,6 +115,8 @@ def load_library() -> C.CDLL:
         "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "lgh_bench_hbm_read": (C.c_int, [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]),
+        "lgh_gguf_inspect": (C.c_int, [C.c_char_p, C.POINTER(GgufInfo), C.c_char_p, sz]),
+        "lgh_load_gguf": (C.c_int, [C.c_char_p, u32, C.c_int, u32, u32, u32, C.POINTER(vp), C.c_char_p, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -171,6 +178,23 @@ class HipGpuInference:
         except Exception:
             self.close()
             raise
+        return self
+
+    @classmethod
+    def from_gguf(cls, path: str, max_seq_len: int = 0, device: int = 0, layer_range: Optional[Sequence[int]] = None,
+                  flags: int = 0) -> "HipGpuInference":
+        """GGUF -> HBM direct load (lgh_load_gguf): header parsed and tensors uploaded by the library itself."""
+        L = load_library()
+        info = gguf_inspect(path)
+        self = cls()
+        err = C.create_string_buffer(512)
+        lb, le = (0, 0) if layer_range is None else (layer_range[0], layer_range[1])
+        rc = L.lgh_load_gguf(path.encode(), int(max_seq_len), device, flags, lb, le, C.byref(self._h), err, len(err))
+        if rc:
+            raise BackendError(rc, "lgh_load_gguf: " + err.value.decode(errors="replace"))
+        d = info["desc"]
+        self.vocab_size, self.hidden_size = d["vocab_size"], d["hidden_size"]
+        self.config = None
         return self
 
     def upload_tensor(self, name: str, ggml_type: int, ne: Iterable[int], data: np.ndarray) -> None:
@@ -377,3 +401,15 @@ def bench_hbm_read(nbytes: int = 1 << 30, iters: int = 10, device: int = 0) -> f
     out = C.c_double(0.0)
     _chk(load_library().lgh_bench_hbm_read(device, nbytes, iters, C.byref(out)), "bench_hbm_read")
     return float(out.value)
+
+
+def gguf_inspect(path: str) -> dict:
+    """Header of a GGUF file as the loader sees it (no GPU needed): version, counts, architecture, model description."""
+    info = GgufInfo()
+    err = C.create_string_buffer(512)
+    rc = load_library().lgh_gguf_inspect(path.encode(), C.byref(info), err, len(err))
+    if rc:
+        raise BackendError(rc, "lgh_gguf_inspect: " + err.value.decode(errors="replace"))
+    return {"version": info.version, "alignment": info.alignment, "n_tensors": info.n_tensors, "n_kv": info.n_kv,
+            "data_offset": info.data_offset, "file_bytes": info.file_bytes, "architecture": info.architecture.decode(),
+            "desc": {n: getattr(info.desc, n) for n, _ in ModelDesc._fields_}}
