@@ -294,6 +294,14 @@ def run_pipeline(args, pkg):
 
 def main():
     args = parse_args()
+    # ONE JSON line on stdout, nothing else: native libraries write banners to fd 1 (RCCL prints its version block there
+    # at communicator creation), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    out = sys.stdout
+    sys.stdout = os.fdopen(saved_stdout, "w", buffering=1)
+    del out
     pkg = graft.load_package()
     from importlib import import_module
     pkg.pipeline = import_module("llama_gguf_amd.pipeline")
