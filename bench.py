@@ -236,7 +236,7 @@ def run_pipeline(args, pkg):
     dev = torch.device("cuda", local)
     dist.init_process_group("nccl", device_id=dev)
     W, K = args.warmup, args.steps
-    max_seq = max(512, args.prompt + W + K + 16)
+    max_seq = max(512, args.prompt + W + K + min(args.profile_steps, 8) + 16)
     cfg = pkg.make_config(args.model, max_seq_len=max_seq)
     model = pkg.SynthModel(cfg, mix=args.mix)
     lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
