@@ -707,8 +707,8 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   }
   c->stream = c->own_stream;
   uint32_t splits = (d.flags >> LGH_FLAG_ATTN_SPLITS_SHIFT) & 0xFFu;
-  if (!splits) {  // aim at ~128 attention workgroups
-    splits = 128 / d.num_kv_heads;
+  if (!splits) {  // one attention workgroup per CU (measured: 605 vs 596 tokens/s at kv 272 and 470 vs 383 at kv 4000 against 128 workgroups)
+    splits = 256 / d.num_kv_heads;
     if (splits < 1) splits = 1;
     if (splits > 32) splits = 32;
   }
