@@ -24,15 +24,17 @@ namespace lgh {
 
 constexpr float kNegBig = -1e30f;
 
-template <int D, int G>
-__global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+// NW waves per workgroup (positions are dealt round-robin over splits x waves): 4 is faster at short context (608 vs 600
+// tokens/s at kv 272), 8 at long (543 vs 524 at kv 4000); the launcher picks by the cache capacity.
+template <int D, int G, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
                                                            const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
                                                            float* __restrict__ part_ml, float* __restrict__ part_acc) {
   constexpr int LPR = D / 4;       // lanes per row
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
-  __shared__ float s_ml[4][G][2];
-  __shared__ float s_acc[4][G][D];
+  __shared__ float s_ml[NW][G][2];
+  __shared__ float s_acc[NW][G][D];
 
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -57,7 +59,7 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
 
   const float* kbase = kc + (size_t)kvh * max_seq * D + li * 4;
   const float* vbase = vc + (size_t)kvh * max_seq * D + li * 4;
-  const uint32_t stride = n_splits * 4 * RPW;
+  const uint32_t stride = n_splits * NW * RPW;
   auto row_of = [&](uint32_t base) { const uint32_t p = base + sub; return p < kv_len ? p : kv_len - 1; };   // clamped: loads are unconditional
   auto step = [&](uint32_t base, f32x4 k4, f32x4 v4) {
     const bool valid = base + sub < kv_len;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
   // end, so the loads are unconditional).  At decode lengths a workgroup has 1-3 iterations and everything is in flight
   // at once; at 4K context it has ~30, and with a single iteration ahead the kernel ran at 1 TB/s (latency-bound).
   constexpr int kAhead = 4;   // (8 measured slower: 604 / 518 vs 614 / 528 tokens/s at kv 272 / 4000)
-  for (uint32_t base = (sp * 4 + wave) * RPW; base < kv_len; base += kAhead * stride) {
+  for (uint32_t base = (sp * NW + wave) * RPW; base < kv_len; base += kAhead * stride) {
     f32x4 kk[kAhead], vv[kAhead];
 #pragma unroll
     for (int j = 0; j < kAhead; j++) {
@@ -124,16 +126,16 @@ __global__ void __launch_bounds__(256) attn_partial_kernel(const float* __restri
     }
   }
   __syncthreads();
-  // merge the 4 waves; thread t handles output elements t, t+256, ...
+  // merge the NW waves; thread t handles output elements t, t + 64 NW, ...
   const size_t pbase = ((size_t)kvh * n_splits + sp) * G;
-  for (uint32_t e = threadIdx.x; e < (uint32_t)(G * D); e += 256) {
+  for (uint32_t e = threadIdx.x; e < (uint32_t)(G * D); e += NW * 64) {
     const uint32_t g = e / D, dim = e % D;
     float mn = s_ml[0][g][0];
 #pragma unroll
-    for (int w = 1; w < 4; w++) mn = fmaxf(mn, s_ml[w][g][0]);
+    for (int w = 1; w < NW; w++) mn = fmaxf(mn, s_ml[w][g][0]);
     float lsum = 0.0f, a = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NW; w++) {
       const float f = expf(s_ml[w][g][0] - mn);
       lsum += s_ml[w][g][1] * f;
       a += s_acc[w][g][dim] * f;
@@ -185,8 +187,13 @@ template <int D, int G>
 static hipError_t attn_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale,
                           const int* pos, int kv_len_fixed, uint32_t n_splits, float* part_ml, float* part_acc,
                           hipStream_t st) {
-  hipLaunchKernelGGL((attn_partial_kernel<D, G>), dim3(n_kv * n_splits), dim3(256), 0, st, q, kc, vc, max_seq, scale, pos,
-                     kv_len_fixed, n_splits, part_ml, part_acc);
+  const bool long_ctx = (pos ? max_seq : (uint32_t)kv_len_fixed) >= 2048;
+  if (long_ctx)
+    hipLaunchKernelGGL((attn_partial_kernel<D, G, 8>), dim3(n_kv * n_splits), dim3(512), 0, st, q, kc, vc, max_seq, scale, pos,
+                       kv_len_fixed, n_splits, part_ml, part_acc);
+  else
+    hipLaunchKernelGGL((attn_partial_kernel<D, G, 4>), dim3(n_kv * n_splits), dim3(256), 0, st, q, kc, vc, max_seq, scale, pos,
+                       kv_len_fixed, n_splits, part_ml, part_acc);
   return hipGetLastError();
 }
 
