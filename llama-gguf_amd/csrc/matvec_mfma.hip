@@ -1,21 +1,20 @@
-// matvec_mfma.hip — Q4_K mat-vec on the int8 matrix cores (v_mfma_i32_16x16x64_i8), exact integer dots.
+// matvec_mfma.hip — quantized mat-vec on the int8 matrix cores (v_mfma_i32_16x16x64_i8): Q4_K, Q5_K, Q6_K, Q8_0, Q4_0.
 //
 // Why MFMA for a mat-VEC.  The VALU formulation (matvec.hip) needs ~3.6 vector instructions per weight
 // (byte->f32 convert, FMA, nibble masks); measured on MI355X a wave64 v_cvt_f32_ubyte costs ~2.0 ns and a
-// v_fma ~1.2 ns of SIMD time with 4 waves per SIMD (tools/probes/mfma_i8_probe.hip), which makes Llama-3-8B
-// Q4_K_M decode ISSUE-bound at ~0.76 ms/token — the same launch takes 21 us whether its 66 MB of weights come
-// from HBM or from the Infinity Cache.  The matrix pipe is a separate issue port: one 16x16x64 int8 MFMA
-// multiplies 1024 weights in ~15 ns, so the multiply-accumulates move there and the VALU only unpacks nibbles
-// (one v_and per 4 weights) and applies scales.
+// v_fma ~1.2 ns of SIMD time with 4 waves per SIMD (tools/probes/mfma_i8_probe.hip), which made Llama-3-8B
+// Q4_K_M decode ISSUE-bound at ~0.76 ms/token — a launch took 21 us whether its 66 MB of weights came from HBM or
+// from the Infinity Cache.  The matrix pipe is a separate issue port: one 16x16x64 int8 MFMA multiplies 1024
+// weights in ~15 ns, so the multiply-accumulates move there and the VALU only unpacks quants and applies scales.
 //
-// Arithmetic (the reference keeps x in f32, src/backend/cpu/simd.rs:978-1032; there is no activation
-// quantization to mirror): every 256-element block of x is split EXACTLY into four signed 7-bit limbs with a
-// power-of-two block scale,  x = s * (l1*2^-6 + l2*2^-13 + l3*2^-20 + l4*2^-27),  |residual| <= 2^-28 * s.
-// The limbs are the A operand (rows 0-3 = group 2p, rows 4-7 = group 2p+1 of a block-diagonal 16x64 tile), 16
-// weight rows x 64 nibbles are the B operand, and D holds sum_k q_k*l_i,k as exact int32.  Per 32-element
-// sub-block the four limb sums are recombined in f32 (V = D0*2^24 + D1*2^16 + D2*2^8 + D3) and scaled by
-// d*sc*s*2^-30; the min term uses f32 sums of x per sub-block, exactly as the reference's x_acc.
-// Error vs the reference's sequential f32 sum is below f32 rounding noise and independent of summation order.
+// Arithmetic (the reference keeps x in f32, src/backend/cpu/simd.rs:978-1032; there is no activation quantization
+// to mirror): x arrives as XQ records (xq.h) — per 16-element chunk x = s * 2^-30 * I with I = d3*2^24 + d2*2^16 +
+// d1*2^8 + d0, balanced int8 digits, exact for every element within 2^6 of the chunk maximum.  The A operand of an
+// MFMA is block-diagonal over its four k-chunks (rows 4c..4c+3 = the four digits of chunk c), 16 weight rows x 64
+// quants are the B operand, and D holds sum_k q_k * digit_i,k as exact int32 — lane group c gets chunk c.  The four
+// digit sums are recombined once in f32 (V = D0*2^24 + D1*2^16 + D2*2^8 + D3) and scaled by d*sc*s*2^-30; min terms
+// (Q4_K, Q5_K) and offsets (Q6_K -32, Q4_0 -8) go through the f32 sums of x per chunk, the reference's x_acc.
+// Error vs the reference's sequential f32 sum is at f32 rounding level and independent of summation order.
 //
 // Device layout "tile16" (same bytes as GGUF, rows padded to 16): a tile = 16 rows x one 256-element block = 2304 B.
 // The nibbles of MFMA step pp (elements 64pp .. 64pp+63) and k-chunk c (16 elements) of row n belong to lane 16c + n,
