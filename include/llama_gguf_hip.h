@@ -87,6 +87,7 @@ typedef struct lgh_model_desc {
 enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
   LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
+  LGH_FLAG_EXACT_PREFILL = 1u << 2,  /* lgh_prefill_batch feeds the tokens one by one (f32 throughout) instead of the batched f16 GEMM path */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8     /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
 };
 
@@ -173,8 +174,14 @@ void lgh_destroy(lgh_ctx* ctx);
 int lgh_forward(lgh_ctx* ctx, uint32_t token_id, float* logits_out);
 /* GpuInference::prefill_token (gpu_only.rs:792-806) */
 int lgh_prefill_token(lgh_ctx* ctx, uint32_t token_id);
-/* GpuOnlyInference::forward_batch minus the last token (gpu_only.rs:776-790): n prefill_tokens */
+/* GpuOnlyInference::forward_batch minus the last token (gpu_only.rs:776-790: n prefill_tokens).  Dense single-stage
+ * models whose 2-D weights are all in matrix-core tile layouts (Q4_K, Q5_K, Q6_K, Q8_0, Q4_0 with k % 256 == 0) take
+ * the batched path: blocks of up to 128 tokens, one f16-MFMA GEMM per weight, causal attention over the
+ * block; the KV cache it leaves equals the token-by-token one within 1e-2 relative (f16 operands, f32 accumulation).
+ * Everything else, and any context created with LGH_FLAG_EXACT_PREFILL, runs n exact prefill_tokens. */
 int lgh_prefill_batch(lgh_ctx* ctx, const uint32_t* tokens, size_t n);
+/* 1 when lgh_prefill_batch will take the batched GEMM path for this (finalized) context, else 0 */
+int lgh_prefill_is_batched(lgh_ctx* ctx);
 /* GpuInference::reset (gpu_only.rs:808-843) — O(1): only the position is rewound (model/mod.rs:110-117) */
 void lgh_reset(lgh_ctx* ctx);
 /* GpuInference::position (gpu_only.rs:845-847) */
@@ -214,6 +221,9 @@ int lgh_stage_forward(lgh_ctx* ctx, uint32_t token_id, int want_logits, float* l
 int lgh_op_dequantize(int device, uint32_t ggml_type, const void* src, size_t n_elems, float* dst);
 /* Backend::vec_mat_q / vec_mat: out[j] = sum_i x[i] * W[i,j], W = n rows of k/bs blocks */
 int lgh_op_vec_mat(int device, uint32_t ggml_type, const void* w, const float* x, float* out, size_t k, size_t n);
+/* out[m][n] = x[m][k] . W^T through the batched-prefill GEMM (f16 matrix cores, f32 accumulation; m <= 128, n % 16 == 0,
+ * k % 256 == 0, type in {Q4_K, Q5_K, Q6_K, Q8_0, Q4_0}); no reference counterpart */
+int lgh_op_mat_mat(int device, uint32_t type, const void* w, const float* x, float* out, size_t k, size_t n, size_t m);
 int lgh_op_rms_norm(int device, const float* x, const float* w, float eps, float* out, size_t n);
 /* Backend::rope with seq_len 1: q [n_heads, d], k [n_kv_heads, d] rotated in place */
 int lgh_op_rope(int device, float* q, float* k, size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t pos,

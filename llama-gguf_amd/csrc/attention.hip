@@ -19,6 +19,7 @@
 // kernel this one does not (each skipped term is < 1e-8 of the output scale).
 #include "device_utils.h"
 #include "xq.h"
+#include "prefill.h"
 
 namespace lgh {
 
@@ -26,7 +27,9 @@ constexpr float kNegBig = -1e30f;
 
 // NW waves per workgroup (positions are dealt round-robin over splits x waves): 4 is faster at short context (608 vs 600
 // tokens/s at kv 272), 8 at long (543 vs 524 at kv 4000); the launcher picks by the cache capacity.
-template <int D, int G, int NW>
+// PF (prefill.hip): blockIdx.y = token t of a block of prompt tokens; it sees kv_len_fixed + t cache rows (causal), its
+// query is q + t * n_heads * D, there is one split, and the normalised output goes to part_acc[t][head][D].
+template <int D, int G, int NW, bool PF = false>
 __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
                                                            const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
@@ -42,7 +45,10 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
   // the position word by SCALAR load: the loop bounds depend on it, and a vector load here would be a full memory round
   // trip before the first K/V row can be requested
   uint32_t kv_len = (uint32_t)kv_len_fixed;
-  if (pos_ptr) {
+  if (PF) {
+    kv_len += blockIdx.y;
+    q += (size_t)blockIdx.y * gridDim.x * G * D;   // gridDim.x = kv heads (one split)
+  } else if (pos_ptr) {
     uint32_t pw;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
     kv_len = pw + 1;
@@ -140,8 +146,12 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
       lsum += s_ml[w][g][1] * f;
       a += s_acc[w][g][dim] * f;
     }
-    part_acc[(pbase + g) * D + dim] = a;
-    if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
+    if (PF) {
+      part_acc[((size_t)blockIdx.y * gridDim.x * G + pbase + g) * D + dim] = a * (1.0f / lsum);   // simd.rs:718-720: multiply by 1/sum
+    } else {
+      part_acc[(pbase + g) * D + dim] = a;
+      if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
+    }
   }
 }
 
@@ -205,6 +215,27 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
 #define LGH_ATTN_CASE(DD, GG) \
   if (head_dim == DD && g == GG)  \
     return attn_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, kv_len_fixed, n_splits, part_ml, part_acc, st);
+  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
+  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
+#undef LGH_ATTN_CASE
+  return hipErrorInvalidValue;
+}
+
+template <int D, int G>
+static hipError_t attn_pf_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t pos0,
+                             uint32_t m_tokens, float* out, hipStream_t st) {
+  hipLaunchKernelGGL((attn_partial_kernel<D, G, 4, true>), dim3(n_kv, m_tokens), dim3(256), 0, st, q, kc, vc, max_seq, scale,
+                     (const int*)nullptr, (int)(pos0 + 1), 1u, (float*)nullptr, out);
+  return hipGetLastError();
+}
+
+hipError_t attn_prefill_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
+                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, float* out,
+                               hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || m_tokens == 0) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_ATTN_CASE(DD, GG) \
+  if (head_dim == DD && g == GG) return attn_pf_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos0, m_tokens, out, st);
   LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
   LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
 #undef LGH_ATTN_CASE

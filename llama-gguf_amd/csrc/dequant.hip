@@ -8,6 +8,7 @@
 // reference also expands to f32 at upload (src/backend/cuda/dequant_weights.rs:211-231).
 #include "device_utils.h"
 #include "xq.h"
+#include "prefill.h"
 
 namespace lgh {
 
@@ -172,6 +173,21 @@ hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, fl
   if (!blk_elems(src_type) || (xq && hidden % 256)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, src_type, table, token, dst, hidden,
                      state, xq, xq_nw, xq_ssq);
+  return hipGetLastError();
+}
+
+// rows tokens[0..m) of the table -> dst[m][hidden] (batched prompt processing, prefill.hip)
+__global__ void __launch_bounds__(256) embed_batch_kernel(int type, const uint8_t* __restrict__ table, const int* __restrict__ tokens,
+                                                          float* __restrict__ dst, uint32_t hidden) {
+  const uint64_t row = (uint64_t)(uint32_t)tokens[blockIdx.y];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < hidden) dst[(size_t)blockIdx.y * hidden + i] = deq_any(type, table, row * hidden + i);
+}
+
+hipError_t embed_batch_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t m_tokens,
+                              hipStream_t st) {
+  if (!blk_elems(src_type) || m_tokens == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_batch_kernel, dim3((hidden + 255) / 256, m_tokens), dim3(256), 0, st, src_type, table, tokens, dst, hidden);
   return hipGetLastError();
 }
 

@@ -30,6 +30,15 @@ struct XqBuf { const float* f32 = nullptr; uint8_t* xq = nullptr; float* ssq = n
 // one chained FFN launch (engine.hip: launch_ffn_chain): host copy of the descriptors + their device image
 struct ChainSlot { MvChainHost host; uint8_t* dev = nullptr; bool prepared = false, uploaded = false; };
 
+// scratch of the batched prompt path (prefill.hip), allocated at the first lgh_prefill_batch that uses it
+struct PfScratch {
+  bool ready = false;
+  uint8_t *xh_h = nullptr, *xh_attn = nullptr, *xh_act = nullptr;   // XH activations: [128][hidden], [128][QD], [128][ffn]
+  float *hidden = nullptr, *q = nullptr, *attn = nullptr, *part = nullptr;
+  size_t part_bytes = 0;
+  int* tokens = nullptr;
+};
+
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
 }  // namespace lgh
@@ -69,6 +78,7 @@ struct lgh_ctx {
   std::vector<lgh::ChainSlot> chains;          // [graph mode][layer]
   std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
   unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
+  lgh::PfScratch pf;
 };
 
 // ---- helpers shared by engine.hip and ops_api.hip ----

@@ -15,6 +15,7 @@
 //                                                            arg-max back on device
 //   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
 #include "engine.h"
+#include "prefill.h"
 #include "xq.h"
 
 #include <algorithm>
@@ -672,6 +673,97 @@ static int set_token(lgh_ctx* c, uint32_t token) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// batched prompt processing (prefill.hip)
+// ------------------------------------------------------------------------------------------------
+static bool pf_eligible(const lgh_ctx* c) {
+  const lgh_model_desc& d = c->d;
+  if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last || d.use_neox_rope) return false;
+  const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
+  if (d.hidden_size % 256 || QD % 256 || d.intermediate_size % 256 || KD % 16) return false;
+  if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
+  for (uint32_t i = c->l0; i < c->l1; i++) {
+    const LayerW& L = c->layers[i];
+    if (L.moe()) return false;
+    for (const DevWeight* W : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down})
+      if (!pf_supported_type(W->type) || W->n % 16) return false;
+  }
+  return true;
+}
+
+static int pf_ensure(lgh_ctx* c) {
+  PfScratch& P = c->pf;
+  if (P.ready) return LGH_OK;
+  const lgh_model_desc& d = c->d;
+  const uint32_t H = d.hidden_size, QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, F = d.intermediate_size;
+  const uint32_t qkv[3] = {QD, KD, KD}, one[1] = {H}, gu[2] = {F, F};
+  size_t pb = pf_part_bytes(qkv, 3, H);
+  pb = std::max(pb, pf_part_bytes(one, 1, QD));
+  pb = std::max(pb, pf_part_bytes(gu, 2, H));
+  pb = std::max(pb, pf_part_bytes(one, 1, F));
+  int rc;
+  struct { void** p; size_t n; } bufs[] = {
+      {(void**)&P.xh_h, xh_bytes(H)},           {(void**)&P.xh_attn, xh_bytes(QD)},
+      {(void**)&P.xh_act, xh_bytes(F)},         {(void**)&P.hidden, (size_t)kPfTokens * H * 4},
+      {(void**)&P.q, (size_t)kPfTokens * QD * 4}, {(void**)&P.attn, (size_t)kPfTokens * QD * 4},
+      {(void**)&P.part, pb},                    {(void**)&P.tokens, (size_t)kPfTokens * 4},
+  };
+  for (auto& b : bufs) {
+    if ((rc = dev_alloc(c, b.p, b.n))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
+    c->stats.scratch_bytes += b.n;
+  }
+  P.part_bytes = pb;
+  P.ready = true;
+  return LGH_OK;
+}
+
+// m <= 128 prompt tokens at positions pos .. pos+m-1: fills every layer's K/V rows (nothing else of a prefill survives)
+static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
+  int rc = pf_ensure(c);
+  if (rc) return rc;
+  PfScratch& P = c->pf;
+  const lgh_model_desc& d = c->d;
+  const uint32_t H = d.hidden_size, QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, F = d.intermediate_size;
+  const uint32_t pos0 = (uint32_t)c->pos;
+  hipStream_t st = c->stream;
+  auto K = [&](hipError_t e, const char* what) -> int {
+    return e == hipSuccess ? LGH_OK : fail(c, LGH_OPERATION_FAILED, std::string("batched prefill, ") + what + ": " + hipGetErrorString(e));
+  };
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, tokens, (size_t)m * 4, hipMemcpyHostToDevice, st));
+  if ((rc = K(embed_batch_launch(c->embd_type, c->embd_raw, P.tokens, P.hidden, H, m, st), "embedding"))) return rc;
+  if ((rc = K(pf_row_epi_launch(nullptr, 0, 0, 0, nullptr, P.hidden, H, c->layers[c->l0].attn_norm, d.norm_eps, P.xh_h, m, st), "attn_norm"))) return rc;
+  const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
+  for (uint32_t li = c->l0; li < c->l1; li++) {
+    LayerW& L = c->layers[li];
+    uint32_t S = 0, nc = 0;
+    const DevWeight* qkv[3] = {&L.wq, &L.wk, &L.wv};
+    if ((rc = K(pf_gemm_launch(qkv, 3, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "qkv GEMM"))) return rc;
+    if ((rc = K(pf_qkv_epi_launch(P.part, S, nc, QD, KD, d.head_dim, L.bq, L.bk, L.bv, c->rope_cs, pos0, d.max_seq_len, P.q, L.kcache, L.vcache, m, st),
+                "qkv epilogue")))
+      return rc;
+    if (li + 1 == c->l1) break;   // the last layer's K/V rows are written; its output would be discarded (prefill has no logits)
+    if ((rc = K(attn_prefill_launch(P.q, L.kcache, L.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, pos0, m, P.attn, st),
+                "attention")))
+      return rc;
+    if ((rc = K(pf_to_xh_launch(P.attn, QD, P.xh_attn, m, st), "attention output"))) return rc;
+    const DevWeight* wo[1] = {&L.wo};
+    if ((rc = K(pf_gemm_launch(wo, 1, P.xh_attn, P.part, P.part_bytes, m, &S, &nc, st), "wo GEMM"))) return rc;
+    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, L.bo, P.hidden, H, L.ffn_norm, d.norm_eps, P.xh_h, m, st), "wo epilogue"))) return rc;
+    const DevWeight* gu[2] = {&L.gate, &L.up};
+    if ((rc = K(pf_gemm_launch(gu, 2, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "gate/up GEMM"))) return rc;
+    if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, m, st), "SwiGLU"))) return rc;
+    const DevWeight* dn[1] = {&L.down};
+    if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, m, &S, &nc, st), "down GEMM"))) return rc;
+    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, c->layers[li + 1].attn_norm, d.norm_eps, P.xh_h, m, st), "down epilogue")))
+      return rc;
+  }
+  c->pos += m;
+  c->stats.tokens_processed += m;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), (int)c->pos, 1, st));
+  return LGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
 extern "C" {
@@ -958,10 +1050,22 @@ int lgh_prefill_token(lgh_ctx* c, uint32_t token) {
   return step(c, MODE_PREFILL);
 }
 
+int lgh_prefill_is_batched(lgh_ctx* c) { return c && c->finalized && pf_eligible(c) ? 1 : 0; }
+
 int lgh_prefill_batch(lgh_ctx* c, const uint32_t* tokens, size_t n) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (n && !tokens) return fail(c, LGH_INVALID_ARGUMENT, "tokens is NULL");
+  if (n >= 2 && pf_eligible(c)) {
+    if (c->pos + n > c->d.max_seq_len)
+      return fail(c, LGH_INVALID_ARGUMENT, "prompt of " + std::to_string(n) + " tokens at position " + std::to_string(c->pos) + " exceeds max_seq_len");
+    for (size_t i = 0; i < n; i++)
+      if (tokens[i] >= c->d.vocab_size) return fail(c, LGH_INVALID_ARGUMENT, "token id exceeds vocab size");
+    for (size_t i = 0; i < n; i += kPfTokens)
+      if ((rc = prefill_block(c, tokens + i, (uint32_t)std::min<size_t>(kPfTokens, n - i)))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+    return LGH_OK;
+  }
   for (size_t i = 0; i < n; i++)
     if ((rc = lgh_prefill_token(c, tokens[i]))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));

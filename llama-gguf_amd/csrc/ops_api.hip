@@ -3,6 +3,7 @@
 // micro-benchmark.  They run the SAME kernels the engine runs, on a throw-away context, so that each
 // kernel can be checked against the CPU backend in isolation.
 #include "engine.h"
+#include "prefill.h"
 
 #include <cmath>
 #include <vector>
@@ -118,6 +119,35 @@ int lgh_op_norm_vec_mat(int device, uint32_t type, const void* w, const float* x
 int lgh_op_swiglu_vec_mat(int device, uint32_t type, const void* w_gate, const void* w_up, const float* x,
                           const float* norm_w, float eps, float* out, size_t k, size_t n) {
   return vec_mat_impl(device, type, w_gate, w_up, x, norm_w, eps, nullptr, out, k, n);
+}
+
+// out[m][n] = x[m][k] . W^T on the batched-prefill GEMM path (prefill.hip): f16 operands, f32 accumulation
+int lgh_op_mat_mat(int device, uint32_t type, const void* w, const float* x, float* out, size_t k, size_t n, size_t m) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  const uint32_t be = blk_elems((int)type);
+  if (!be || k % be || m == 0 || m > (size_t)kPfTokens) return LGH_SHAPE_MISMATCH;
+  const size_t nbytes = n * (k / be) * blk_bytes((int)type);
+  DevWeight W;
+  int rc;
+  if ((rc = upload_matrix(t.c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
+  if (!pf_supported_type(W.type) || n % 16) return LGH_UNSUPPORTED;
+  const uint32_t nr[1] = {(uint32_t)n};
+  const size_t pb = pf_part_bytes(nr, 1, (uint32_t)k);
+  float* dx = t.up(x, m * k);
+  float* dout = t.up(nullptr, (size_t)kPfTokens * n);
+  uint8_t* xh = nullptr;
+  float* part = nullptr;
+  if (!dx || !dout || dev_alloc(t.c, (void**)&xh, xh_bytes((uint32_t)k)) || dev_alloc(t.c, (void**)&part, pb)) return LGH_ALLOCATION_FAILED;
+  hipStream_t st = t.c->stream;
+  if (hipMemsetAsync(dout, 0, (size_t)kPfTokens * n * 4, st) != hipSuccess || hipMemsetAsync(xh, 0, xh_bytes((uint32_t)k), st) != hipSuccess)
+    return LGH_OPERATION_FAILED;
+  const DevWeight* Ws[1] = {&W};
+  uint32_t S = 0, nc = 0;
+  if (pf_to_xh_launch(dx, (uint32_t)k, xh, (uint32_t)m, st) != hipSuccess) return LGH_OPERATION_FAILED;
+  if (pf_gemm_launch(Ws, 1, xh, part, pb, (uint32_t)m, &S, &nc, st) != hipSuccess) return LGH_OPERATION_FAILED;
+  if (pf_row_epi_launch(part, S, nc, 0, nullptr, dout, (uint32_t)n, nullptr, 1e-5f, nullptr, (uint32_t)m, st) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, m * n);
 }
 
 int lgh_op_rms_norm(int device, const float* x, const float* w, float eps, float* out, size_t n) {

@@ -1,0 +1,51 @@
+// prefill.h — batched prompt processing on the f16 matrix cores (prefill.hip; internal).
+#pragma once
+
+#include "common.h"
+
+namespace lgh {
+
+constexpr int kPfTokens = 128;                    // tokens per pass = rows of an XH activation matrix
+constexpr uint32_t kPfSlabBytes = kPfTokens * 512;   // one 256-element slab of XH: 128 tokens x 256 f16
+
+inline size_t xh_bytes(uint32_t k) { return (size_t)(k / 256) * kPfSlabBytes; }
+
+struct PfSeg {
+  const uint8_t* w;      // tile16 weights
+  uint32_t ntiles;       // 16-row tiles
+  uint32_t col0;         // first column in the partial-sum rows
+  uint32_t rg_begin;     // first row group (workgroup x index) of this matrix
+  int fmt;
+};
+
+struct PfGemm {
+  PfSeg seg[3];
+  int nseg;
+  uint32_t nblk;         // 256-element blocks of k
+  uint32_t S;            // k-splits (gridDim.y)
+  uint32_t ncols;        // floats per partial-sum row
+  const uint8_t* xh;     // input activations [128][k] f16, XH layout
+  float* part;           // [S][128][ncols]
+  uint32_t m_tiles;      // token tiles that hold real tokens
+};
+
+bool pf_supported_type(int dev_type);
+size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k);
+hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
+                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st);
+hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
+                             const float* nw, float eps, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
+hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
+                             const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
+                             float* kcache, float* vcache, uint32_t m_tokens, hipStream_t st);
+hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
+hipError_t pf_to_xh_launch(const float* x, uint32_t K, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
+// dequant.hip: rows tokens[0..m) of the embedding table -> dst[m][hidden]
+hipError_t embed_batch_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t m_tokens,
+                              hipStream_t st);
+// attention.hip: causal attention of a block of m tokens at positions pos0 .. pos0+m-1 (their K/V rows already cached)
+hipError_t attn_prefill_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
+                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, float* out,
+                               hipStream_t st);
+
+}  // namespace lgh

@@ -1,0 +1,500 @@
+// prefill.hip — batched prompt processing: up to 128 prompt tokens per pass as one GEMM per weight on the f16 matrix
+// cores (v_mfma_f32_16x16x32_f16), causal attention over the block, everything else row-wise.
+//
+// The reference has no counterpart: its prefill is `prefill_token` once per prompt token (src/backend/cuda/gpu_only.rs:
+// 776-806; CPU: src/model/llama.rs:327-345), i.e. the whole model is streamed from memory once per token.  Here the
+// quantized weights are read ONCE per 128 tokens.  This is the one place where f16 rounding enters the engine: the
+// activations and the dequantized weights are rounded to f16 (11 significant bits each) in front of the matrix cores,
+// products are accumulated in f32.  The KV cache it leaves must equal the one left by the same tokens fed one by one
+// within the stated tolerance (tests/test_gpu_prefill.py); the exact token-by-token path stays available
+// (LGH_FLAG_EXACT_PREFILL).
+//
+// Data flow per layer (all launches on the context's stream, nothing is captured in a graph):
+//   XH(h * attn_norm/rms) --GEMM wq|wk|wv--> partial sums --pf_qkv_epi--> q [M][QD] f32, K/V cache rows pos0 .. pos0+M-1
+//   q, cache --pf attention (attention.hip, causal: token t sees pos0 + t + 1 rows)--> XH(attn)
+//   XH(attn) --GEMM wo--> partials --pf_row_epi(+bias, +residual, RMSNorm ffn_norm)--> h, XH(h * ffn_norm/rms)
+//   XH --GEMM gate|up--> partials --pf_swiglu--> XH(act) --GEMM down--> partials --pf_row_epi(next attn_norm)--> h, XH
+//
+// "XH": an activation matrix [128 tokens][K] in f16, laid out for the GEMM's B operand: one 64 KB slab per 256
+// elements of K (copied verbatim into LDS by LDS-DMA), inside a slab token t owns 512 B = 32 chunks of 8 elements, chunk
+// q stored at position q ^ (t & 15) (so that the 16 tokens of an MFMA operand read 16 different LDS banks groups), inside
+// a chunk the elements are in the order 0,2,1,3,4,6,5,7 (the order in which two masks pull nibbles out of a tile16 word).
+//
+// GEMM: a workgroup = 4 waves = 256 weight rows x one k-range x all 128 tokens; a wave = 4 row tiles (64 rows): weights
+// go HBM -> registers -> f16 (never through LDS: the dequantized lane layout IS the A operand), an activation fragment
+// read from LDS feeds 4 MFMAs (LDS at 50 % of its bandwidth), 128 f32 accumulators per lane.  K is split over
+// gridDim.y workgroups to fill the chip; the f32 partial sums [split][token][column] are added up by the row-wise
+// kernel that consumes them (together with bias, RoPE, residual, RMSNorm, SwiGLU).
+// Weights are dequantized as w * 2^8 (kPfScale) to keep small block scales out of the f16 subnormals; |w| < 256 is
+// assumed (f16 overflow otherwise) — GGUF weights are O(1).
+#include "device_utils.h"
+#include "mv_epilogue.h"
+#include "prefill.h"
+
+namespace lgh {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// formats as in matvec_mfma.hip (same tile16 layouts)
+enum : int { PF_Q4K = 0, PF_Q6K = 1, PF_Q5K = 2, PF_Q80 = 3, PF_Q40 = 4 };
+__host__ __device__ constexpr uint32_t pf_tile_bytes(int f) {
+  return f == PF_Q4K ? 2304u : f == PF_Q6K ? 3392u : f == PF_Q5K ? 2816u : f == PF_Q80 ? 4352u : 2304u;
+}
+static int pf_fmt_of(int dev_type) {
+  return dev_type == kDevQ4K_T16 ? PF_Q4K : dev_type == kDevQ6K_T16 ? PF_Q6K : dev_type == kDevQ5K_T16 ? PF_Q5K
+         : dev_type == kDevQ80_T16 ? PF_Q80 : dev_type == kDevQ40_T16 ? PF_Q40 : -1;
+}
+
+constexpr int kPfRT = 4;                 // row tiles per wave
+constexpr int kPfWaves = 4;
+constexpr int kPfMT = kPfTokens / 16;    // token tiles
+constexpr float kPfScale = 256.0f;
+
+struct PfRaw { u32x4 hd; u32x4 q[4]; };
+
+template <int F>
+__device__ __forceinline__ void pf_load(PfRaw& r, const uint8_t* tile, uint32_t lane, uint32_t n) {
+  if (F == PF_Q6K) {
+    r.hd = ldg_nt128(tile + 3072 + n * 16);
+#pragma unroll
+    for (int i = 0; i < 3; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
+    r.q[3].x = ldg_nt32(tile + 3328 + (n >> 1) * 4);
+  } else if (F == PF_Q80) {
+    r.hd = ldg_nt128(tile + 4096 + n * 16);
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.q[i] = ldg_nt128(tile + i * 1024 + lane * 16);
+  } else {
+    r.hd = ldg_nt128(tile + 2048 + n * 16);
+    r.q[0] = ldg_nt128(tile + lane * 16);
+    r.q[1] = ldg_nt128(tile + 1024 + lane * 16);
+    if (F == PF_Q5K) {
+      const u32x2 h = ldg_nt64(tile + 2304 + lane * 8);
+      r.q[2].x = h.x;
+      r.q[2].y = h.y;
+    }
+  }
+}
+
+__device__ __forceinline__ h16x2 pf_bcast(float v) {
+  const _Float16 h = (_Float16)v;
+  h16x2 r = {h, h};
+  return r;
+}
+
+// scale S and offset O (both times kPfScale, as f16 pairs) of MFMA step pp of the lane's row n and k-chunk c:
+// weight = S * u + O with u the unsigned stored quant
+template <int F>
+__device__ __forceinline__ void pf_scale(const PfRaw& r, int pp, uint32_t n, uint32_t c, h16x2& S, h16x2& O) {
+  if (F == PF_Q6K) {   // y = d * sc * (q' - 32), one int8 scale per 16 elements (dequant.rs:321-356)
+    const uint32_t hdw = pp == 0 ? r.hd.x : pp == 1 ? r.hd.y : pp == 2 ? r.hd.z : r.hd.w;
+    const float scf = (float)(int)__builtin_amdgcn_sbfe((int)hdw, c * 8, 8);
+    const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
+    S = pf_bcast(h2f(dh) * scf * kPfScale);
+    O = S * pf_bcast(-32.0f);
+  } else if (F == PF_Q80 || F == PF_Q40) {   // y = d * q (Q8_0, stored q + 128 after the sign flip) / d * (q - 8) (Q4_0)
+    const uint32_t hdw = pp == 0 ? r.hd.x : pp == 1 ? r.hd.y : pp == 2 ? r.hd.z : r.hd.w;
+    const float dd = h2f((c >> 1) ? hdw >> 16 : hdw & 0xFFFFu);
+    S = pf_bcast(dd * kPfScale);
+    O = S * pf_bcast(F == PF_Q80 ? -128.0f : -8.0f);
+  } else {   // Q4_K / Q5_K: y = d * sc * q - dmin * m, 6-bit (sc, m) per 32 elements (dequant.rs:210-255)
+    const uint32_t s8 = (c >> 1) * 8;
+    const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
+    uint32_t sc, mn;
+    if (pp < 2) {
+      const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
+      sc = pp == 0 ? sc01 & 0xFFu : sc01 >> 16;
+      mn = pp == 0 ? mn01 & 0xFFu : mn01 >> 16;
+    } else {
+      const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
+      const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
+      sc = pp == 2 ? sc23 & 0xFFu : sc23 >> 16;
+      mn = pp == 2 ? mn23 & 0xFFu : mn23 >> 16;
+    }
+    const float dd = h2f(r.hd.x & 0xFFFFu), dmin = h2f(r.hd.x >> 16);
+    S = pf_bcast(dd * (float)sc * kPfScale);
+    O = pf_bcast(-(dmin * (float)mn) * kPfScale);
+  }
+}
+
+__device__ __forceinline__ h16x2 pf_fin(uint32_t bits, h16x2 S, h16x2 O) {
+  const h16x2 k = {(_Float16)1024.0f, (_Float16)1024.0f};
+  const h16x2 u = __builtin_bit_cast(h16x2, bits) - k;   // 0x6400 | u  ==  1024 + u exactly
+  return __builtin_elementwise_fma(u, S, O);
+}
+
+__device__ __forceinline__ h16x8 pf_pack(h16x2 a, h16x2 b, h16x2 c, h16x2 d) {
+  h16x8 r = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+  return r;
+}
+
+// eight nibbles (word byte t = w[t] | w[t+4] << 4) -> f16 in the order w0 w2 w1 w3 w4 w6 w5 w7
+__device__ __forceinline__ h16x8 pf_frag_nib(uint32_t N, h16x2 S, h16x2 O) {
+  const uint32_t m = 0x000F000Fu, e = 0x64006400u;
+  return pf_pack(pf_fin((N & m) | e, S, O), pf_fin(((N >> 8) & m) | e, S, O), pf_fin(((N >> 4) & m) | e, S, O),
+                 pf_fin(((N >> 12) & m) | e, S, O));
+}
+// eight bytes (B0 = w0..w3, B1 = w4..w7) -> f16 in the same order
+__device__ __forceinline__ h16x8 pf_frag_bytes(uint32_t B0, uint32_t B1, h16x2 S, h16x2 O) {
+  const uint32_t e = 0x64646464u;
+  return pf_pack(pf_fin(__builtin_amdgcn_perm(e, B0, 0x04020400u), S, O), pf_fin(__builtin_amdgcn_perm(e, B0, 0x04030401u), S, O),
+                 pf_fin(__builtin_amdgcn_perm(e, B1, 0x04020400u), S, O), pf_fin(__builtin_amdgcn_perm(e, B1, 0x04030401u), S, O));
+}
+
+// the A operand of MFMA (pp, h): elements 64pp + 16c + 8h .. +7 of row n, dequantized
+template <int F>
+__device__ __forceinline__ h16x8 pf_frag(const PfRaw& r, int pp, int h, h16x2 S, h16x2 O) {
+  if (F == PF_Q80) {
+    const u32x4 b = r.q[pp];
+    const uint32_t B0 = (h ? b.z : b.x) ^ 0x80808080u, B1 = (h ? b.w : b.y) ^ 0x80808080u;
+    return pf_frag_bytes(B0, B1, S, O);
+  }
+  const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+  const uint32_t N = h ? N1 : N0;
+  if (F == PF_Q4K || F == PF_Q40) return pf_frag_nib(N, S, O);
+  uint32_t B0 = N & 0x0F0F0F0Fu, B1 = (N >> 4) & 0x0F0F0F0Fu;
+  if (F == PF_Q6K) {   // H byte t = f[t] | f[t+4] << 2 | f[t+8] << 4 | f[t+12] << 6 (the two high bits of the chunk's 16 weights)
+    const uint32_t H = pp == 0 ? r.q[2].x : pp == 1 ? r.q[2].y : pp == 2 ? r.q[2].z : r.q[2].w;
+    B0 |= ((H >> (4 * h)) & 0x03030303u) << 4;
+    B1 |= ((H >> (4 * h + 2)) & 0x03030303u) << 4;
+  } else {             // Q5_K: fifth bits, dword of the step pair, low nibbles = even step, high nibbles = odd step
+    const uint32_t H = ((pp >> 1) ? r.q[2].y : r.q[2].x) >> (4 * (pp & 1));
+    B0 |= ((H >> (2 * h)) & 0x01010101u) << 4;
+    B1 |= ((H >> (2 * h + 1)) & 0x01010101u) << 4;
+  }
+  return pf_frag_bytes(B0, B1, S, O);
+}
+
+template <int F>
+__device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32_t rg, uint32_t ks, uint8_t* smem) {
+  const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n = lane & 15, c = lane >> 4;
+  constexpr uint32_t tb = pf_tile_bytes(F);
+  // this split's k-blocks
+  const uint32_t per = (G.nblk + G.S - 1) / G.S;
+  const uint32_t b0 = ks * per, b1 = b0 + per < G.nblk ? b0 + per : G.nblk;
+  const uint32_t tile0 = (rg * kPfWaves + wave) * kPfRT;
+  const uint8_t* wt[kPfRT];
+#pragma unroll
+  for (int r = 0; r < kPfRT; r++) {
+    const uint32_t tl = tile0 + r < sg.ntiles ? tile0 + r : sg.ntiles - 1;   // clamped: loads are unconditional
+    wt[r] = sg.w + (size_t)tl * G.nblk * tb;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+
+  f32x4 acc[kPfRT][kPfMT];
+#pragma unroll
+  for (int r = 0; r < kPfRT; r++)
+#pragma unroll
+    for (int t = 0; t < kPfMT; t++) acc[r][t] = (f32x4)(0.0f);
+
+  // one 64 KB slab -> LDS buffer `buf`: this wave's quarter, 16 x 1 KB by LDS-DMA (no registers)
+  auto x_dma = [&](uint32_t b, uint32_t buf) {
+    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * 16384 + lane * 16;
+    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * 16384;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + i * 1024), "s"(dst + i * 1024) : "memory");
+    }
+  };
+
+  PfRaw nxt[kPfRT];
+  if (b0 < b1) {
+    x_dma(b0, 0);
+#pragma unroll
+    for (int r = 0; r < kPfRT; r++) pf_load<F>(nxt[r], wt[r] + (size_t)b0 * tb, lane, n);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (uint32_t b = b0; b < b1; b++) {
+    const uint32_t cur = (b - b0) & 1;
+    PfRaw w[kPfRT];
+#pragma unroll
+    for (int r = 0; r < kPfRT; r++) w[r] = nxt[r];
+    if (b + 1 < b1) x_dma(b + 1, cur ^ 1);
+    {
+      const uint32_t bn = b + 1 < b1 ? b + 1 : b;   // the last iteration re-requests its own block (unconditional loads)
+#pragma unroll
+      for (int r = 0; r < kPfRT; r++) pf_load<F>(nxt[r], wt[r] + (size_t)bn * tb, lane, n);
+    }
+    const uint8_t* xb = smem + cur * kPfSlabBytes + n * 512;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      h16x2 S[kPfRT], O[kPfRT];
+#pragma unroll
+      for (int r = 0; r < kPfRT; r++) pf_scale<F>(w[r], pp, n, c, S[r], O[r]);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const uint32_t q = (uint32_t)(pp * 8 + h) + c * 2;
+        h16x8 bf[kPfMT];
+#pragma unroll
+        for (int t = 0; t < kPfMT; t++) bf[t] = *reinterpret_cast<const h16x8*>(xb + t * 8192 + ((q ^ n) << 4));
+#pragma unroll
+        for (int r = 0; r < kPfRT; r++) {
+          const h16x8 a = pf_frag<F>(w[r], pp, h, S[r], O[r]);
+#pragma unroll
+          for (int t = 0; t < kPfMT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[t], acc[r][t], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  // partial sums: lane holds, per (row tile, token tile), rows 4c .. 4c+3 of token n
+  float* part = G.part + (size_t)ks * kPfTokens * G.ncols;
+#pragma unroll
+  for (int r = 0; r < kPfRT; r++) {
+    if (tile0 + r >= sg.ntiles) continue;
+    const uint32_t col = sg.col0 + (tile0 + r) * 16 + c * 4;
+#pragma unroll
+    for (int t = 0; t < kPfMT; t++) {
+      if ((uint32_t)t >= G.m_tiles) continue;
+      const f32x4 v = acc[r][t] * (1.0f / kPfScale);
+      *reinterpret_cast<f32x4*>(part + (size_t)(t * 16 + n) * G.ncols + col) = v;
+    }
+  }
+}
+
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kPfWaves * 64) pf_gemm_kernel(const PfGemm G) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
+  const uint32_t rgid = blockIdx.x;
+  int si = 0;
+  if (G.nseg > 1 && rgid >= G.seg[1].rg_begin) si = 1;
+  if (G.nseg > 2 && rgid >= G.seg[2].rg_begin) si = 2;
+  const PfSeg& sg = G.seg[si];
+  const uint32_t rg = rgid - sg.rg_begin;
+  auto is = [&](int f) { return (MASK & (1u << f)) && (MASK == (1u << f) || sg.fmt == f); };
+  if (is(PF_Q4K)) pf_body<PF_Q4K>(G, sg, rg, blockIdx.y, pf_smem);
+  else if (is(PF_Q6K)) pf_body<PF_Q6K>(G, sg, rg, blockIdx.y, pf_smem);
+  else if (is(PF_Q5K)) pf_body<PF_Q5K>(G, sg, rg, blockIdx.y, pf_smem);
+  else if (is(PF_Q80)) pf_body<PF_Q80>(G, sg, rg, blockIdx.y, pf_smem);
+  else if (is(PF_Q40)) pf_body<PF_Q40>(G, sg, rg, blockIdx.y, pf_smem);
+}
+
+template <uint32_t MASK>
+static hipError_t pf_gemm_go(const PfGemm& G, uint32_t n_rg, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t lds = 2 * kPfSlabBytes;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pf_gemm_kernel<MASK>), dim3(n_rg, G.S), dim3(kPfWaves * 64), lds, st, G);
+  return hipGetLastError();
+}
+
+bool pf_supported_type(int dev_type) { return pf_fmt_of(dev_type) >= 0; }
+
+// k-splits of a GEMM over matrices with n_rows[i] rows and k columns: as many as keep the launch within one workgroup per CU
+static void pf_plan(const uint32_t* n_rows, int nw, uint32_t k, uint32_t* rg_out, uint32_t* S_out) {
+  const uint32_t nblk = k / 256;
+  uint32_t rg = 0;
+  for (int i = 0; i < nw; i++) rg += (n_rows[i] / 16 + kPfWaves * kPfRT - 1) / (kPfWaves * kPfRT);
+  uint32_t S = rg >= (uint32_t)kNumCU ? 1 : kNumCU / rg;
+  if (S > nblk) S = nblk;
+  const uint32_t per = (nblk + S - 1) / S;
+  *S_out = (nblk + per - 1) / per;
+  *rg_out = rg;
+}
+
+// bytes of partial sums such a GEMM writes
+size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k) {
+  uint32_t rg, S, cols = 0;
+  pf_plan(n_rows, nw, k, &rg, &S);
+  for (int i = 0; i < nw; i++) cols += n_rows[i];
+  return (size_t)S * kPfTokens * cols * 4;
+}
+
+// Plans and launches one GEMM: up to 3 weight matrices that share the input XH (k elements per token), outputs side by
+// side in the partial-sum buffer.  Returns the split count through *S_out (the consumer adds that many partials).
+hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
+                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st) {
+  if (nw < 1 || nw > 3 || m_tokens == 0 || m_tokens > (uint32_t)kPfTokens) return hipErrorInvalidValue;
+  PfGemm G{};
+  const uint32_t k = W[0]->k;
+  if (k % 256) return hipErrorInvalidValue;
+  G.nseg = nw;
+  G.nblk = k / 256;
+  uint32_t rg = 0, col = 0, mask = 0, n_rows[3] = {0, 0, 0};
+  for (int i = 0; i < nw; i++) {
+    const int f = pf_fmt_of(W[i]->type);
+    if (f < 0 || W[i]->k != k || W[i]->n % 16 || W[i]->n_stack != 1) return hipErrorInvalidValue;
+    G.seg[i].w = W[i]->plane[0];
+    G.seg[i].ntiles = W[i]->n / 16;
+    G.seg[i].col0 = col;
+    G.seg[i].rg_begin = rg;
+    G.seg[i].fmt = f;
+    mask |= 1u << f;
+    rg += (G.seg[i].ntiles + kPfWaves * kPfRT - 1) / (kPfWaves * kPfRT);
+    col += W[i]->n;
+    n_rows[i] = W[i]->n;
+  }
+  uint32_t rg2;
+  pf_plan(n_rows, nw, k, &rg2, &G.S);
+  G.ncols = col;
+  G.xh = xh;
+  G.part = part;
+  G.m_tiles = (m_tokens + 15) / 16;
+  if ((size_t)G.S * kPfTokens * col * 4 > part_bytes) return hipErrorInvalidValue;
+  *S_out = G.S;
+  *ncols_out = col;
+  switch (mask) {
+    case 1u << PF_Q4K: return pf_gemm_go<1u << PF_Q4K>(G, rg, st);
+    case 1u << PF_Q6K: return pf_gemm_go<1u << PF_Q6K>(G, rg, st);
+    case (1u << PF_Q4K) | (1u << PF_Q6K): return pf_gemm_go<(1u << PF_Q4K) | (1u << PF_Q6K)>(G, rg, st);
+    case 1u << PF_Q5K: return pf_gemm_go<1u << PF_Q5K>(G, rg, st);
+    case (1u << PF_Q5K) | (1u << PF_Q6K): return pf_gemm_go<(1u << PF_Q5K) | (1u << PF_Q6K)>(G, rg, st);
+    case 1u << PF_Q80: return pf_gemm_go<1u << PF_Q80>(G, rg, st);
+    case 1u << PF_Q40: return pf_gemm_go<1u << PF_Q40>(G, rg, st);
+    default: return pf_gemm_go<31u>(G, rg, st);   // any other mix of the five formats
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// XH writers and the row-wise kernels between the GEMMs
+// ------------------------------------------------------------------------------------------------
+// chunk `ch` (8 consecutive elements starting at 8*ch) of token t
+__device__ __forceinline__ void xh_store_chunk(uint8_t* xh, uint32_t t, uint32_t ch, const float v[8]) {
+  const uint32_t b = ch >> 5, q = ch & 31;
+  h16x8 o = {(_Float16)v[0], (_Float16)v[2], (_Float16)v[1], (_Float16)v[3], (_Float16)v[4], (_Float16)v[6], (_Float16)v[5], (_Float16)v[7]};
+  *reinterpret_cast<h16x8*>(xh + (size_t)b * kPfSlabBytes + t * 512 + ((q ^ (t & 15)) << 4)) = o;
+}
+
+// One workgroup per token.  v[i] = sum_s part[s][t][col0 + i] (+ bias[i]) (+ resid[t][i]); hidden[t][i] = v[i] (when
+// there are partials); then XH[t][i] = f16((v[i] * inv_rms) * nw[i]) (simd.rs:847-878: (x * inv) * w).
+// S == 0: no partials, v = hidden[t][i] (the embedding rows).
+__global__ void __launch_bounds__(256) pf_row_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t col0,
+                                                         const float* __restrict__ bias, float* __restrict__ hidden, uint32_t H,
+                                                         const float* __restrict__ nw, float eps, uint8_t* __restrict__ xh) {
+  extern __shared__ float pf_row[];
+  __shared__ float s_ss[4];
+  const uint32_t t = blockIdx.x;
+  float ss = 0.0f;
+  for (uint32_t i = threadIdx.x; i < H; i += 256) {
+    float v;
+    if (S == 0) {
+      v = hidden[(size_t)t * H + i];
+    } else {
+      v = 0.0f;
+      for (uint32_t s = 0; s < S; s++) v += part[((size_t)s * kPfTokens + t) * ncols + col0 + i];
+      if (bias) v += bias[i];
+      v += hidden[(size_t)t * H + i];   // residual (layers.rs:1201-1208, 1235-1241)
+      hidden[(size_t)t * H + i] = v;
+    }
+    pf_row[i] = v;
+    ss = __builtin_fmaf(v, v, ss);
+  }
+  if (!xh) return;
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+  const float inv = 1.0f / __builtin_sqrtf(tot / (float)H + eps);
+  for (uint32_t ch = threadIdx.x; ch < H / 8; ch += 256) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (pf_row[ch * 8 + j] * inv) * nw[ch * 8 + j];
+    xh_store_chunk(xh, t, ch, v);
+  }
+}
+
+hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
+                             const float* nw, float eps, uint8_t* xh, uint32_t m_tokens, hipStream_t st) {
+  if (H % 8 || (xh && !nw)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_row_epi_kernel, dim3(m_tokens), dim3(256), (size_t)H * 4, st, part, S, ncols, col0, bias, hidden, H, nw, eps, xh);
+  return hipGetLastError();
+}
+
+// q, k, v of token t: partial sums (+bias), RoPE on the (2i, 2i+1) pairs of q and k at position pos0 + t
+// (ops.rs:1285-1337), q -> qbuf[t][QD], k / v -> cache rows pos0 + t (layers.rs:577-600)
+__global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD,
+                                                         uint32_t head_dim, const float* __restrict__ bq, const float* __restrict__ bk,
+                                                         const float* __restrict__ bv, const float* __restrict__ rope_cs, uint32_t pos0,
+                                                         uint32_t max_seq, float* __restrict__ qbuf, float* __restrict__ kcache,
+                                                         float* __restrict__ vcache) {
+  const uint32_t t = blockIdx.x, pos = pos0 + t, half = head_dim / 2;
+  const uint32_t npairs = (QD + 2 * KD) / 2;
+  for (uint32_t p = threadIdx.x; p < npairs; p += 256) {
+    const uint32_t col = 2 * p;
+    float x0 = 0.0f, x1 = 0.0f;
+    for (uint32_t s = 0; s < S; s++) {
+      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * kPfTokens + t) * ncols + col);
+      x0 += v.x;
+      x1 += v.y;
+    }
+    if (col < QD + KD) {
+      const bool isq = col < QD;
+      const uint32_t row = isq ? col : col - QD;
+      const float* b = isq ? bq : bk;
+      if (b) { x0 += b[row]; x1 += b[row + 1]; }
+      const uint32_t i = (row % head_dim) / 2;
+      const float cs = rope_cs[((size_t)pos * half + i) * 2], sn = rope_cs[((size_t)pos * half + i) * 2 + 1];
+      const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
+      float* dst = isq ? qbuf + (size_t)t * QD + row : kcache + ((size_t)(row / head_dim) * max_seq + pos) * head_dim + (row % head_dim);
+      dst[0] = y0;
+      dst[1] = y1;
+    } else {
+      const uint32_t row = col - QD - KD;
+      if (bv) { x0 += bv[row]; x1 += bv[row + 1]; }
+      float* dst = vcache + ((size_t)(row / head_dim) * max_seq + pos) * head_dim + (row % head_dim);
+      dst[0] = x0;
+      dst[1] = x1;
+    }
+  }
+}
+
+hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
+                             const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
+                             float* kcache, float* vcache, uint32_t m_tokens, hipStream_t st) {
+  if (head_dim % 2 || ncols != QD + 2 * KD) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_qkv_epi_kernel, dim3(m_tokens), dim3(256), 0, st, part, S, ncols, QD, KD, head_dim, bq, bk, bv, rope_cs, pos0, max_seq,
+                     qbuf, kcache, vcache);
+  return hipGetLastError();
+}
+
+// act = silu(gate) * up (simd.rs:598-649) from the partial sums (gate in columns [0, F), up in [F, 2F)) -> XH[t][F]
+__global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict__ part, uint32_t S, uint32_t F, uint8_t* __restrict__ xh) {
+  const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= F / 8) return;
+  float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t s = 0; s < S; s++) {
+    const float* row = part + ((size_t)s * kPfTokens + t) * (2 * (size_t)F);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(row + ch * 8), g1 = *reinterpret_cast<const f32x4*>(row + ch * 8 + 4);
+    const f32x4 u0 = *reinterpret_cast<const f32x4*>(row + F + ch * 8), u1 = *reinterpret_cast<const f32x4*>(row + F + ch * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { g[j] += g0[j]; g[4 + j] += g1[j]; u[j] += u0[j]; u[4 + j] += u1[j]; }
+  }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = silu_f(g[j]) * u[j];
+  xh_store_chunk(xh, t, ch, v);
+}
+
+hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, uint32_t m_tokens, hipStream_t st) {
+  if (F % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_swiglu_kernel, dim3((F / 8 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, F, xh);
+  return hipGetLastError();
+}
+
+// plain f32 [M][K] -> XH (no scaling): the attention output in front of wo
+__global__ void __launch_bounds__(256) pf_to_xh_kernel(const float* __restrict__ x, uint32_t K, uint8_t* __restrict__ xh) {
+  const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= K / 8) return;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = x[(size_t)t * K + ch * 8 + j];
+  xh_store_chunk(xh, t, ch, v);
+}
+
+hipError_t pf_to_xh_launch(const float* x, uint32_t K, uint8_t* xh, uint32_t m_tokens, hipStream_t st) {
+  if (K % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_to_xh_kernel, dim3((K / 8 + 255) / 256, m_tokens), dim3(256), 0, st, x, K, xh);
+  return hipGetLastError();
+}
+
+}  // namespace lgh

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip%s.so" % ("_" + os.envir
 # every symbol include/llama_gguf_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "lgh_device_count", "lgh_create", "lgh_upload_tensor", "lgh_finalize", "lgh_destroy", "lgh_forward",
-    "lgh_prefill_token", "lgh_prefill_batch", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
+    "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
@@ -39,6 +39,7 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
              "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>")
 FLAG_NO_GRAPH = 1
+FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
 
@@ -97,7 +98,8 @@ def load_library() -> C.CDLL:
         "lgh_upload_tensor": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(C.c_uint64), vp, sz]),
         "lgh_finalize": (C.c_int, [vp]), "lgh_destroy": (None, [vp]),
         "lgh_forward": (C.c_int, [vp, u32, vp]), "lgh_prefill_token": (C.c_int, [vp, u32]),
-        "lgh_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_reset": (None, [vp]), "lgh_position": (sz, [vp]),
+        "lgh_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_prefill_is_batched": (C.c_int, [vp]),
+        "lgh_op_mat_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, sz, sz, sz]), "lgh_reset": (None, [vp]), "lgh_position": (sz, [vp]),
         "lgh_forward_argmax": (C.c_int, [vp, u32, C.POINTER(u32)]),
         "lgh_decode_greedy": (C.c_int, [vp, u32, sz, vp]),
         "lgh_last_error": (C.c_char_p, [vp]), "lgh_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
@@ -220,6 +222,9 @@ class HipGpuInference:
         toks = np.ascontiguousarray(tokens, dtype=np.uint32)
         self._call(load_library().lgh_prefill_batch(self._h, toks.ctypes.data, toks.size))
 
+    def prefill_is_batched(self) -> bool:
+        return bool(load_library().lgh_prefill_is_batched(self._h))
+
     def reset(self) -> None:
         load_library().lgh_reset(self._h)
 
@@ -334,6 +339,15 @@ def op_vec_mat(ggml_type: int, w: np.ndarray, x, n: int, device: int = 0) -> np.
     w, x = np.ascontiguousarray(w), _f32(x)
     out = np.empty(n, dtype=np.float32)
     _chk(load_library().lgh_op_vec_mat(device, ggml_type, w.ctypes.data, x.ctypes.data, out.ctypes.data, x.size, n), "vec_mat")
+    return out
+
+
+def op_mat_mat(ggml_type: int, w: np.ndarray, x, n: int, device: int = 0) -> np.ndarray:
+    """x [m][k] . W^T -> [m][n] on the batched-prefill GEMM path (f16 matrix cores, f32 accumulation)."""
+    w, x = np.ascontiguousarray(w), _f32(x)
+    m, k = x.shape
+    out = np.empty((m, n), dtype=np.float32)
+    _chk(load_library().lgh_op_mat_mat(device, ggml_type, w.ctypes.data, x.ctypes.data, out.ctypes.data, k, n, m), "mat_mat")
     return out
 
 

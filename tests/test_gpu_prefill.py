@@ -1,0 +1,159 @@
+"""Batched prompt processing on the MI355X: the f16-MFMA GEMM path behind lgh_prefill_batch.
+
+The reference has no batched prefill (gpu_only.rs:776-806 feeds the prompt token by token), so the contract is the
+one SURVEY §8(a16) states: the result must equal N sequential `prefill_token`s within 1e-2 relative — this is the one
+place f16 rounding enters (operands rounded to 11 significant bits, f32 accumulation).  The exact path (f32 throughout)
+is the comparison target, and the CPU oracle behind it.
+
+Stated tolerances:
+  GEMM alone     max|d| <= 1e-2 * max|y|  and  rms(d) <= 2e-3 * rms(y)        (measured: ~3e-4 * rms)
+  logits after   max|d| <= 1e-2 * max|logit| + 1e-2 against the exact engine and against the oracle
+  greedy tokens  identical whenever the top-1/top-2 gap exceeds 4x the measured logit error"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FUSED = ["Q4_K", "Q5_K", "Q6_K", "Q8_0", "Q4_0"]
+
+
+def _weights(pkg, tname, k, n, name="blk.0.test.weight"):
+    t = pkg.synth.TYPE_IDS[tname]
+    return t, pkg.synth.fill_tensor(name, t, k * n, k)
+
+
+def _check_gemm(got, want):
+    d = got.astype(np.float64) - want
+    rms_y = float(np.sqrt(np.mean(want ** 2)))
+    assert np.abs(d).max() <= 1e-2 * np.abs(want).max(), f"max|d| {np.abs(d).max():.3e} vs max|y| {np.abs(want).max():.3e}"
+    assert float(np.sqrt(np.mean(d ** 2))) <= 2e-3 * rms_y
+    return float(np.sqrt(np.mean(d ** 2))) / rms_y
+
+
+@pytest.mark.parametrize("tname", FUSED)
+@pytest.mark.parametrize("k,n,m", [(256, 16, 1), (1024, 272, 37), (2048, 64, 128), (5632, 80, 100), (4096, 1040, 128)])
+def test_mat_mat_matches_dequantized_product(gpu, pkg, orc, tname, k, n, m):
+    """One block / ragged token counts / uneven k-splits (22 blocks) / more than one row group and several splits."""
+    t, raw = _weights(pkg, tname, k, n)
+    x = np.random.default_rng(k + n + m).standard_normal((m, k)).astype(np.float32)
+    w = orc.dequantize(t, raw, k * n).reshape(n, k).astype(np.float64)
+    want = x.astype(np.float64) @ w.T
+    got = gpu.op_mat_mat(t, raw, x, n)
+    rel = _check_gemm(got, want)
+    print(f"{tname} k={k} n={n} m={m}: rms(d)/rms(y) = {rel:.2e}")
+
+
+def test_mat_mat_full_size_rows_are_independent_and_deterministic(gpu, pkg, orc):
+    """Llama-3-8B gate shape: token rows do not leak into each other, zero rows give exact zeros, and the result is
+    run-to-run identical; spot columns against the oracle's dequantized weights."""
+    k, n, m = 4096, 14336, 128
+    t, raw = _weights(pkg, "Q4_K", k, n)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    x[5] = 0.0
+    y = gpu.op_mat_mat(t, raw, x, n)
+    assert np.all(y[5] == 0.0)
+    assert np.array_equal(y, gpu.op_mat_mat(t, raw, x, n))
+    y1 = gpu.op_mat_mat(t, raw, x[40:41], n)                 # the same token alone (m = 1)
+    assert np.array_equal(y1[0], y[40])
+    rb = orc.nbytes_for(t, k)
+    cols = rng.integers(0, n, 48)
+    w = np.stack([orc.dequantize(t, raw[j * rb:(j + 1) * rb], k) for j in cols]).astype(np.float64)
+    _check_gemm(y[:, cols], x.astype(np.float64) @ w.T)
+
+
+def _pair(pkg, orc, name, mix, max_seq, flags_b=0):
+    cfg = pkg.make_config(name, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=mix)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    exact = pkg.HipGpuInference.from_model(model, max_seq, flags=pkg.hip_backend.FLAG_EXACT_PREFILL)
+    batched = pkg.HipGpuInference.from_model(model, max_seq, flags=flags_b)
+    return cfg, ref, exact, batched
+
+
+def _tol(want):
+    return 1e-2 * float(np.abs(want).max()) + 1e-2
+
+
+@pytest.mark.parametrize("name,mix,n_prompt", [("test-dense", "Q4_K_M", 41), ("test-dense", "Q8_0", 128), ("test-dense", "Q4_0", 17),
+                                               ("test-dense", "Q5_K_M", 64), ("test-dense", "Q6_K", 33),
+                                               ("test-dense-d128", "Q4_K_M", 150), ("test-dense-d128", "Q5_K_M", 129)])
+def test_batched_prefill_matches_token_by_token_and_oracle(pkg, orc, name, mix, n_prompt):
+    """The KV cache left by the batched path, seen through the logits of the following tokens."""
+    cfg, ref, exact, batched = _pair(pkg, orc, name, mix, max_seq=256)
+    assert batched.prefill_is_batched() and not exact.prefill_is_batched()
+    prompt = [(7 * i + 3) % cfg.vocab_size for i in range(n_prompt)]
+    exact.forward_batch(prompt[:-1])
+    batched.forward_batch(prompt[:-1])
+    assert exact.position() == batched.position() == n_prompt - 1
+    want_o = ref.forward(prompt)
+    errs, gaps = [], []
+    tok = prompt[-1]
+    for step in range(12):
+        le, lb = exact.forward(tok), batched.forward(tok)
+        if step == 0:
+            assert np.abs(lb - want_o).max() <= _tol(want_o)      # against the CPU oracle, not only our own exact path
+        errs.append(float(np.abs(lb - le).max()))
+        assert errs[-1] <= _tol(le)
+        srt = np.sort(le)
+        gaps.append(float(srt[-1] - srt[-2]))
+        te, tb = orc.argmax_last(le), orc.argmax_last(lb)
+        if gaps[-1] > 4 * errs[-1]:
+            assert te == tb, f"greedy token diverged with gap {gaps[-1]:.3e} vs err {errs[-1]:.3e}"
+        tok = te
+    print(f"{name}/{mix} prompt {n_prompt}: max|dlogit|={max(errs):.3e} tol={_tol(le):.3e} min_gap={min(gaps):.3e}")
+    exact.close()
+    batched.close()
+
+
+def test_batched_prefill_continues_an_existing_sequence(pkg, orc):
+    """forward_batch at position > 0 (a second turn): causal attention over the block sees the earlier cache rows."""
+    cfg, ref, exact, batched = _pair(pkg, orc, "test-dense", "Q4_K_M", max_seq=128)
+    a, b = [(5 * i + 1) % cfg.vocab_size for i in range(20)], [(11 * i + 2) % cfg.vocab_size for i in range(30)]
+    for eng in (exact, batched):
+        eng.forward_batch(a)
+        eng.forward(77)
+        eng.forward_batch(b)
+        assert eng.position() == 51
+    le, lb = exact.forward(9), batched.forward(9)
+    assert np.abs(lb - le).max() <= _tol(le)
+    batched.reset()
+    exact.reset()
+    exact.forward_batch(a)
+    batched.forward_batch(a)                                   # after reset: rows 0.. are rewritten
+    le, lb = exact.forward(9), batched.forward(9)
+    assert np.abs(lb - le).max() <= _tol(le)
+    exact.close()
+    batched.close()
+
+
+def test_models_outside_the_batched_path_prefill_exactly(pkg, orc):
+    """MoE layers (and any format mix without tile layouts) keep the token-by-token path: bit-identical to prefill_token."""
+    cfg = pkg.make_config("test-moe", max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix="Q5_K_M")
+    a, b = pkg.HipGpuInference.from_model(model, 64), pkg.HipGpuInference.from_model(model, 64)
+    assert not a.prefill_is_batched()
+    prompt = [3, 500, 41, 7, 900, 12]
+    a.forward_batch(prompt)
+    for t in prompt:
+        b.prefill_token(t)
+    assert np.array_equal(a.forward(5), b.forward(5))
+    a.close()
+    b.close()
+
+
+def test_batched_prefill_rejects_a_prompt_beyond_the_cache(pkg):
+    cfg = pkg.make_config("test-dense", max_seq_len=32)
+    eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix="Q4_K_M"), 32)
+    eng.forward_batch([1, 2, 3])
+    with pytest.raises(pkg.BackendError) as ei:
+        eng.forward_batch(list(range(40)))
+    assert ei.value.variant == "InvalidArgument"
+    assert eng.position() == 3                                  # nothing was written
+    with pytest.raises(pkg.BackendError):
+        eng.forward_batch([1, cfg.vocab_size + 5])
+    assert eng.position() == 3
+    eng.close()
