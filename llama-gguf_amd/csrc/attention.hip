@@ -28,7 +28,8 @@ constexpr float kNegBig = -1e30f;
 // NW waves per workgroup (positions are dealt round-robin over splits x waves): 4 is faster at short context (608 vs 600
 // tokens/s at kv 272), 8 at long (543 vs 524 at kv 4000); the launcher picks by the cache capacity.
 // PF (prefill.hip): blockIdx.y = token t of a block of prompt tokens; it sees kv_len_fixed + t cache rows (causal), its
-// query is q + t * n_heads * D, there is one split, and the normalised output goes to part_acc[t][head][D].
+// query is q + t * n_heads * D, there is one split, and the normalised output goes, as f16, into the XH matrix at
+// `part_acc` (prefill.h: the wo GEMM's input).
 template <int D, int G, int NW, bool PF = false>
 __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
@@ -147,7 +148,8 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
       a += s_acc[w][g][dim] * f;
     }
     if (PF) {
-      part_acc[((size_t)blockIdx.y * gridDim.x * G + pbase + g) * D + dim] = a * (1.0f / lsum);   // simd.rs:718-720: multiply by 1/sum
+      const _Float16 o = (_Float16)(a * (1.0f / lsum));   // simd.rs:718-720: multiply by 1/sum
+      *reinterpret_cast<_Float16*>(reinterpret_cast<uint8_t*>(part_acc) + xh_offset(blockIdx.y, (uint32_t)(pbase + g) * D + dim)) = o;
     } else {
       part_acc[(pbase + g) * D + dim] = a;
       if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
@@ -223,19 +225,19 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
 
 template <int D, int G>
 static hipError_t attn_pf_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale, uint32_t pos0,
-                             uint32_t m_tokens, float* out, hipStream_t st) {
+                             uint32_t m_tokens, uint8_t* xh_out, hipStream_t st) {
   hipLaunchKernelGGL((attn_partial_kernel<D, G, 4, true>), dim3(n_kv, m_tokens), dim3(256), 0, st, q, kc, vc, max_seq, scale,
-                     (const int*)nullptr, (int)(pos0 + 1), 1u, (float*)nullptr, out);
+                     (const int*)nullptr, (int)(pos0 + 1), 1u, (float*)nullptr, reinterpret_cast<float*>(xh_out));
   return hipGetLastError();
 }
 
 hipError_t attn_prefill_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
-                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, float* out,
+                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, uint8_t* xh_out,
                                hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || m_tokens == 0) return hipErrorInvalidValue;
   const uint32_t g = n_heads / n_kv;
 #define LGH_ATTN_CASE(DD, GG) \
-  if (head_dim == DD && g == GG) return attn_pf_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos0, m_tokens, out, st);
+  if (head_dim == DD && g == GG) return attn_pf_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos0, m_tokens, xh_out, st);
   LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
   LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
 #undef LGH_ATTN_CASE

@@ -34,7 +34,7 @@ struct ChainSlot { MvChainHost host; uint8_t* dev = nullptr; bool prepared = fal
 struct PfScratch {
   bool ready = false;
   uint8_t *xh_h = nullptr, *xh_attn = nullptr, *xh_act = nullptr;   // XH activations: [128][hidden], [128][QD], [128][ffn]
-  float *hidden = nullptr, *q = nullptr, *attn = nullptr, *part = nullptr;
+  float *hidden = nullptr, *q = nullptr, *part = nullptr, *ssq = nullptr;
   size_t part_bytes = 0;
   int* tokens = nullptr;
 };

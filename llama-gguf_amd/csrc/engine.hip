@@ -679,7 +679,7 @@ static bool pf_eligible(const lgh_ctx* c) {
   const lgh_model_desc& d = c->d;
   if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last || d.use_neox_rope) return false;
   const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
-  if (d.hidden_size % 256 || QD % 256 || d.intermediate_size % 256 || KD % 16) return false;
+  if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || d.intermediate_size % 256 || KD % 16) return false;
   if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
   for (uint32_t i = c->l0; i < c->l1; i++) {
     const LayerW& L = c->layers[i];
@@ -704,8 +704,9 @@ static int pf_ensure(lgh_ctx* c) {
   struct { void** p; size_t n; } bufs[] = {
       {(void**)&P.xh_h, xh_bytes(H)},           {(void**)&P.xh_attn, xh_bytes(QD)},
       {(void**)&P.xh_act, xh_bytes(F)},         {(void**)&P.hidden, (size_t)kPfTokens * H * 4},
-      {(void**)&P.q, (size_t)kPfTokens * QD * 4}, {(void**)&P.attn, (size_t)kPfTokens * QD * 4},
+      {(void**)&P.q, (size_t)kPfTokens * QD * 4},
       {(void**)&P.part, pb},                    {(void**)&P.tokens, (size_t)kPfTokens * 4},
+      {(void**)&P.ssq, (size_t)kPfTokens * kPfSsqChunks * 4},
   };
   for (auto& b : bufs) {
     if ((rc = dev_alloc(c, b.p, b.n))) return rc;
@@ -731,30 +732,30 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
   };
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, tokens, (size_t)m * 4, hipMemcpyHostToDevice, st));
   if ((rc = K(embed_batch_launch(c->embd_type, c->embd_raw, P.tokens, P.hidden, H, m, st), "embedding"))) return rc;
-  if ((rc = K(pf_row_epi_launch(nullptr, 0, 0, 0, nullptr, P.hidden, H, c->layers[c->l0].attn_norm, d.norm_eps, P.xh_h, m, st), "attn_norm"))) return rc;
+  if ((rc = K(pf_row_epi_launch(nullptr, 0, 0, 0, nullptr, P.hidden, H, c->layers[c->l0].attn_norm, P.xh_h, P.ssq, m, st), "attn_norm"))) return rc;
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   for (uint32_t li = c->l0; li < c->l1; li++) {
     LayerW& L = c->layers[li];
     uint32_t S = 0, nc = 0;
     const DevWeight* qkv[3] = {&L.wq, &L.wk, &L.wv};
     if ((rc = K(pf_gemm_launch(qkv, 3, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "qkv GEMM"))) return rc;
-    if ((rc = K(pf_qkv_epi_launch(P.part, S, nc, QD, KD, d.head_dim, L.bq, L.bk, L.bv, c->rope_cs, pos0, d.max_seq_len, P.q, L.kcache, L.vcache, m, st),
+    if ((rc = K(pf_qkv_epi_launch(P.part, S, nc, QD, KD, d.head_dim, L.bq, L.bk, L.bv, c->rope_cs, pos0, d.max_seq_len, P.q, L.kcache, L.vcache, P.ssq, H,
+                                  d.norm_eps, m, st),
                 "qkv epilogue")))
       return rc;
     if (li + 1 == c->l1) break;   // the last layer's K/V rows are written; its output would be discarded (prefill has no logits)
-    if ((rc = K(attn_prefill_launch(P.q, L.kcache, L.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, pos0, m, P.attn, st),
+    if ((rc = K(attn_prefill_launch(P.q, L.kcache, L.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, pos0, m, P.xh_attn, st),
                 "attention")))
       return rc;
-    if ((rc = K(pf_to_xh_launch(P.attn, QD, P.xh_attn, m, st), "attention output"))) return rc;
     const DevWeight* wo[1] = {&L.wo};
     if ((rc = K(pf_gemm_launch(wo, 1, P.xh_attn, P.part, P.part_bytes, m, &S, &nc, st), "wo GEMM"))) return rc;
-    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, L.bo, P.hidden, H, L.ffn_norm, d.norm_eps, P.xh_h, m, st), "wo epilogue"))) return rc;
+    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, L.bo, P.hidden, H, L.ffn_norm, P.xh_h, P.ssq, m, st), "wo epilogue"))) return rc;
     const DevWeight* gu[2] = {&L.gate, &L.up};
     if ((rc = K(pf_gemm_launch(gu, 2, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "gate/up GEMM"))) return rc;
-    if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, m, st), "SwiGLU"))) return rc;
+    if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, P.ssq, H, d.norm_eps, m, st), "SwiGLU"))) return rc;
     const DevWeight* dn[1] = {&L.down};
     if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, m, &S, &nc, st), "down GEMM"))) return rc;
-    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, c->layers[li + 1].attn_norm, d.norm_eps, P.xh_h, m, st), "down epilogue")))
+    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, c->layers[li + 1].attn_norm, P.xh_h, P.ssq, m, st), "down epilogue")))
       return rc;
   }
   c->pos += m;

@@ -137,8 +137,11 @@ int lgh_op_mat_mat(int device, uint32_t type, const void* w, const float* x, flo
   float* dx = t.up(x, m * k);
   float* dout = t.up(nullptr, (size_t)kPfTokens * n);
   uint8_t* xh = nullptr;
-  float* part = nullptr;
-  if (!dx || !dout || dev_alloc(t.c, (void**)&xh, xh_bytes((uint32_t)k)) || dev_alloc(t.c, (void**)&part, pb)) return LGH_ALLOCATION_FAILED;
+  float *part = nullptr, *ssq = nullptr;
+  if (n > 2048u * kPfSsqChunks) return LGH_UNSUPPORTED;
+  if (!dx || !dout || dev_alloc(t.c, (void**)&xh, xh_bytes((uint32_t)k)) || dev_alloc(t.c, (void**)&part, pb) ||
+      dev_alloc(t.c, (void**)&ssq, (size_t)kPfTokens * kPfSsqChunks * 4))
+    return LGH_ALLOCATION_FAILED;
   hipStream_t st = t.c->stream;
   if (hipMemsetAsync(dout, 0, (size_t)kPfTokens * n * 4, st) != hipSuccess || hipMemsetAsync(xh, 0, xh_bytes((uint32_t)k), st) != hipSuccess)
     return LGH_OPERATION_FAILED;
@@ -146,7 +149,7 @@ int lgh_op_mat_mat(int device, uint32_t type, const void* w, const float* x, flo
   uint32_t S = 0, nc = 0;
   if (pf_to_xh_launch(dx, (uint32_t)k, xh, (uint32_t)m, st) != hipSuccess) return LGH_OPERATION_FAILED;
   if (pf_gemm_launch(Ws, 1, xh, part, pb, (uint32_t)m, &S, &nc, st) != hipSuccess) return LGH_OPERATION_FAILED;
-  if (pf_row_epi_launch(part, S, nc, 0, nullptr, dout, (uint32_t)n, nullptr, 1e-5f, nullptr, (uint32_t)m, st) != hipSuccess) return LGH_OPERATION_FAILED;
+  if (pf_row_epi_launch(part, S, nc, 0, nullptr, dout, (uint32_t)n, nullptr, nullptr, ssq, (uint32_t)m, st) != hipSuccess) return LGH_OPERATION_FAILED;
   return t.down(out, dout, m * n);
 }
 

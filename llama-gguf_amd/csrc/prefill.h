@@ -8,6 +8,8 @@ namespace lgh {
 constexpr int kPfTokens = 128;                    // tokens per pass = rows of an XH activation matrix
 constexpr uint32_t kPfSlabBytes = kPfTokens * 512;   // one 256-element slab of XH: 128 tokens x 256 f16
 
+constexpr int kPfSsqChunks = 8;                   // per-token partial sums of squares (one per 2048 columns): hidden <= 16384
+
 inline size_t xh_bytes(uint32_t k) { return (size_t)(k / 256) * kPfSlabBytes; }
 
 struct PfSeg {
@@ -34,18 +36,24 @@ size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k);
 hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
                           uint32_t* S_out, uint32_t* ncols_out, hipStream_t st);
 hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
-                             const float* nw, float eps, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
+                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st);
 hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
                              const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
-                             float* kcache, float* vcache, uint32_t m_tokens, hipStream_t st);
-hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
+                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, uint32_t m_tokens, hipStream_t st);
+hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, const float* ssq, uint32_t H, float eps, uint32_t m_tokens,
+                            hipStream_t st);
 hipError_t pf_to_xh_launch(const float* x, uint32_t K, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
 // dequant.hip: rows tokens[0..m) of the embedding table -> dst[m][hidden]
 hipError_t embed_batch_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t m_tokens,
                               hipStream_t st);
 // attention.hip: causal attention of a block of m tokens at positions pos0 .. pos0+m-1 (their K/V rows already cached)
 hipError_t attn_prefill_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
-                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, float* out,
+                               uint32_t head_dim, uint32_t max_seq, float scale, uint32_t pos0, uint32_t m_tokens, uint8_t* xh_out,
                                hipStream_t st);
+// byte offset of element k of token t in an XH matrix
+__host__ __device__ inline size_t xh_offset(uint32_t t, uint32_t k) {
+  const uint32_t ch = k >> 3, j = k & 7, pj = (j == 1 || j == 5) ? j + 1 : (j == 2 || j == 6) ? j - 1 : j;
+  return (size_t)(ch >> 5) * kPfSlabBytes + t * 512 + (((ch & 31) ^ (t & 15)) << 4) + pj * 2;
+}
 
 }  // namespace lgh

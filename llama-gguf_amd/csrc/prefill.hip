@@ -10,10 +10,12 @@
 // (LGH_FLAG_EXACT_PREFILL).
 //
 // Data flow per layer (all launches on the context's stream, nothing is captured in a graph):
-//   XH(h * attn_norm/rms) --GEMM wq|wk|wv--> partial sums --pf_qkv_epi--> q [M][QD] f32, K/V cache rows pos0 .. pos0+M-1
-//   q, cache --pf attention (attention.hip, causal: token t sees pos0 + t + 1 rows)--> XH(attn)
-//   XH(attn) --GEMM wo--> partials --pf_row_epi(+bias, +residual, RMSNorm ffn_norm)--> h, XH(h * ffn_norm/rms)
-//   XH --GEMM gate|up--> partials --pf_swiglu--> XH(act) --GEMM down--> partials --pf_row_epi(next attn_norm)--> h, XH
+//   XH(h * attn_norm) --GEMM wq|wk|wv--> partial sums --pf_qkv_epi (x 1/rms, bias, RoPE)--> q [M][QD] f32, K/V cache rows
+//   q, cache --attention (attention.hip, PF variant; causal: token t sees pos0 + t + 1 rows)--> XH(attn)
+//   XH(attn) --GEMM wo--> partials --pf_resid (+bias, +residual)--> h, XH(h * ffn_norm), sums of squares per token
+//   XH --GEMM gate|up--> partials --pf_swiglu (x 1/rms)--> XH(act) --GEMM down--> partials --pf_resid--> h, XH(h * attn_norm')
+// The RMSNorm's 1/rms is a per-token scalar and the GEMM is linear: XH holds h * norm_weight and the kernel that adds
+// up the GEMM's partial sums multiplies by 1/rms (from the sums of squares the producer of h left) — as in the decode path.
 //
 // "XH": an activation matrix [128 tokens][K] in f16, laid out for the GEMM's B operand: one 64 KB slab per 256
 // elements of K (copied verbatim into LDS by LDS-DMA), inside a slab token t owns 512 B = 32 chunks of 8 elements, chunk
@@ -118,28 +120,28 @@ __device__ __forceinline__ void pf_scale(const PfRaw& r, int pp, uint32_t n, uin
   }
 }
 
-__device__ __forceinline__ h16x2 pf_fin(uint32_t bits, h16x2 S, h16x2 O) {
+// four words of two f16 (0x6400 | u == 1024 + u exactly) -> S * u + O.  Stage by stage over the four words (not word by
+// word): a packed-f16 op that consumes the previous instruction's result costs an extra s_nop on gfx950.
+__device__ __forceinline__ h16x8 pf_fin4(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, h16x2 S, h16x2 O) {
   const h16x2 k = {(_Float16)1024.0f, (_Float16)1024.0f};
-  const h16x2 u = __builtin_bit_cast(h16x2, bits) - k;   // 0x6400 | u  ==  1024 + u exactly
-  return __builtin_elementwise_fma(u, S, O);
-}
-
-__device__ __forceinline__ h16x8 pf_pack(h16x2 a, h16x2 b, h16x2 c, h16x2 d) {
-  h16x8 r = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+  const h16x2 u0 = __builtin_bit_cast(h16x2, b0) - k, u1 = __builtin_bit_cast(h16x2, b1) - k;
+  const h16x2 u2 = __builtin_bit_cast(h16x2, b2) - k, u3 = __builtin_bit_cast(h16x2, b3) - k;
+  const h16x2 w0 = __builtin_elementwise_fma(u0, S, O), w1 = __builtin_elementwise_fma(u1, S, O);
+  const h16x2 w2 = __builtin_elementwise_fma(u2, S, O), w3 = __builtin_elementwise_fma(u3, S, O);
+  h16x8 r = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y, w3.x, w3.y};
   return r;
 }
 
 // eight nibbles (word byte t = w[t] | w[t+4] << 4) -> f16 in the order w0 w2 w1 w3 w4 w6 w5 w7
 __device__ __forceinline__ h16x8 pf_frag_nib(uint32_t N, h16x2 S, h16x2 O) {
-  const uint32_t m = 0x000F000Fu, e = 0x64006400u;
-  return pf_pack(pf_fin((N & m) | e, S, O), pf_fin(((N >> 8) & m) | e, S, O), pf_fin(((N >> 4) & m) | e, S, O),
-                 pf_fin(((N >> 12) & m) | e, S, O));
+  const uint32_t m = opaque(0x000F000Fu), e = 0x64006400u;   // mask in a VGPR: (x & m) | e is then one v_and_or_b32
+  return pf_fin4((N & m) | e, ((N >> 8) & m) | e, ((N >> 4) & m) | e, ((N >> 12) & m) | e, S, O);
 }
 // eight bytes (B0 = w0..w3, B1 = w4..w7) -> f16 in the same order
 __device__ __forceinline__ h16x8 pf_frag_bytes(uint32_t B0, uint32_t B1, h16x2 S, h16x2 O) {
   const uint32_t e = 0x64646464u;
-  return pf_pack(pf_fin(__builtin_amdgcn_perm(e, B0, 0x04020400u), S, O), pf_fin(__builtin_amdgcn_perm(e, B0, 0x04030401u), S, O),
-                 pf_fin(__builtin_amdgcn_perm(e, B1, 0x04020400u), S, O), pf_fin(__builtin_amdgcn_perm(e, B1, 0x04030401u), S, O));
+  return pf_fin4(__builtin_amdgcn_perm(e, B0, 0x04020400u), __builtin_amdgcn_perm(e, B0, 0x04030401u),
+                 __builtin_amdgcn_perm(e, B1, 0x04020400u), __builtin_amdgcn_perm(e, B1, 0x04030401u), S, O);
 }
 
 // the A operand of MFMA (pp, h): elements 64pp + 16c + 8h .. +7 of row n, dequantized
@@ -220,25 +222,38 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
 #pragma unroll
       for (int r = 0; r < kPfRT; r++) pf_load<F>(nxt[r], wt[r] + (size_t)bn * tb, lane, n);
     }
+    // The block's 32 units (MFMA step pp, half h, row tile r) as a software pipeline, one scheduling region per unit:
+    // the unit's 8 MFMAs, the dequantization of the NEXT unit's A fragment, and — in the first unit of a (pp, h) phase —
+    // the LDS reads of the next phase's activation fragments.  Measured on Llama-3-8B Q4_K_M (128 tokens, 4.9 ms): with
+    // the LDS reads removed 4.89 ms, with the dequantization removed 4.19 ms — a 16-cycle MFMA holds the vector issue
+    // port for 8 cycles and each of the ~2.7 VALU ops per MFMA for 4 more, so the loop is VALU-issue-bound; forcing an
+    // MFMA / VALU interleave with sched_group_barrier changed nothing (4.94 vs 4.88 ms).
     const uint8_t* xb = smem + cur * kPfSlabBytes + n * 512;
+    h16x8 bf[2][kPfMT];
+    h16x2 S[kPfRT], O[kPfRT];
+    auto read_bf = [&](int ph, h16x8* dst) {
+      const uint32_t q = (uint32_t)((ph >> 1) * 8 + (ph & 1)) + c * 2;
 #pragma unroll
-    for (int pp = 0; pp < 4; pp++) {
-      h16x2 S[kPfRT], O[kPfRT];
+      for (int t = 0; t < kPfMT; t++) dst[t] = *reinterpret_cast<const h16x8*>(xb + t * 8192 + ((q ^ n) << 4));
+    };
+    read_bf(0, bf[0]);
+    pf_scale<F>(w[0], 0, n, c, S[0], O[0]);
+    h16x8 af[2];
+    af[0] = pf_frag<F>(w[0], 0, 0, S[0], O[0]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < kPfRT; r++) pf_scale<F>(w[r], pp, n, c, S[r], O[r]);
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint32_t q = (uint32_t)(pp * 8 + h) + c * 2;
-        h16x8 bf[kPfMT];
-#pragma unroll
-        for (int t = 0; t < kPfMT; t++) bf[t] = *reinterpret_cast<const h16x8*>(xb + t * 8192 + ((q ^ n) << 4));
-#pragma unroll
-        for (int r = 0; r < kPfRT; r++) {
-          const h16x8 a = pf_frag<F>(w[r], pp, h, S[r], O[r]);
-#pragma unroll
-          for (int t = 0; t < kPfMT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[t], acc[r][t], 0, 0, 0);
-        }
+    for (int u = 0; u < 8 * kPfRT; u++) {
+      const int ph = u / kPfRT, r = u % kPfRT;
+      if (u + 1 < 8 * kPfRT) {
+        const int ph2 = (u + 1) / kPfRT, r2 = (u + 1) % kPfRT, pp2 = ph2 >> 1, h2 = ph2 & 1;
+        if (h2 == 0) pf_scale<F>(w[r2], pp2, n, c, S[r2], O[r2]);
+        af[(u + 1) & 1] = pf_frag<F>(w[r2], pp2, h2, S[r2], O[r2]);
       }
+#pragma unroll
+      for (int t = 0; t < kPfMT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1], bf[ph & 1][t], acc[r][t], 0, 0, 0);
+      const bool rd = r == 0 && ph + 1 < 8;
+      if (rd) read_bf(ph + 1, bf[(ph + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -365,48 +380,63 @@ __device__ __forceinline__ void xh_store_chunk(uint8_t* xh, uint32_t t, uint32_t
   *reinterpret_cast<h16x8*>(xh + (size_t)b * kPfSlabBytes + t * 512 + ((q ^ (t & 15)) << 4)) = o;
 }
 
-// One workgroup per token.  v[i] = sum_s part[s][t][col0 + i] (+ bias[i]) (+ resid[t][i]); hidden[t][i] = v[i] (when
-// there are partials); then XH[t][i] = f16((v[i] * inv_rms) * nw[i]) (simd.rs:847-878: (x * inv) * w).
-// S == 0: no partials, v = hidden[t][i] (the embedding rows).
-__global__ void __launch_bounds__(256) pf_row_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t col0,
-                                                         const float* __restrict__ bias, float* __restrict__ hidden, uint32_t H,
-                                                         const float* __restrict__ nw, float eps, uint8_t* __restrict__ xh) {
-  extern __shared__ float pf_row[];
+// 1 / rms of token t from the per-chunk sums of squares its producer left (simd.rs:847-878); 1 when there is no norm
+__device__ __forceinline__ float pf_inv_rms(const float* ssq, uint32_t n_ssq, uint32_t t, uint32_t H, float eps) {
+  if (!ssq) return 1.0f;
+  float tot = 0.0f;
+  for (uint32_t j = 0; j < n_ssq; j++) tot += ssq[t * kPfSsqChunks + j];
+  return 1.0f / __builtin_sqrtf(tot / (float)H + eps);
+}
+
+// Row epilogue, (2048-column chunks) x (tokens) workgroups:
+//   v[i] = sum_s part[s][t][col0 + i] (+ bias[i]) + hidden[t][i]  (the residual, layers.rs:1201-1208, 1235-1241);
+//   hidden[t][i] = v[i];  XH[t][i] = f16(v[i] * nw[i]);  ssq[t][chunk] = sum of v^2 over the chunk.
+// The RMSNorm's 1/rms is a per-token scalar and the GEMM is linear, so it is applied by the kernel that consumes the
+// GEMM's partial sums (pf_inv_rms) — no second pass over the row.  S == 0: v = hidden[t][i] as it is (embedding rows).
+__global__ void __launch_bounds__(256) pf_resid_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t col0,
+                                                       const float* __restrict__ bias, float* __restrict__ hidden, uint32_t H,
+                                                       const float* __restrict__ nw, uint8_t* __restrict__ xh, float* __restrict__ ssq) {
   __shared__ float s_ss[4];
-  const uint32_t t = blockIdx.x;
+  const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x, i = ch * 8;
   float ss = 0.0f;
-  for (uint32_t i = threadIdx.x; i < H; i += 256) {
-    float v;
-    if (S == 0) {
-      v = hidden[(size_t)t * H + i];
-    } else {
-      v = 0.0f;
-      for (uint32_t s = 0; s < S; s++) v += part[((size_t)s * kPfTokens + t) * ncols + col0 + i];
-      if (bias) v += bias[i];
-      v += hidden[(size_t)t * H + i];   // residual (layers.rs:1201-1208, 1235-1241)
-      hidden[(size_t)t * H + i] = v;
+  if (i < H) {
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i), v1 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i + 4);
+    if (S) {
+      f32x4 a0 = (f32x4)(0.0f), a1 = (f32x4)(0.0f);
+      for (uint32_t s = 0; s < S; s++) {
+        const float* row = part + ((size_t)s * kPfTokens + t) * ncols + col0 + i;
+        a0 += *reinterpret_cast<const f32x4*>(row);
+        a1 += *reinterpret_cast<const f32x4*>(row + 4);
+      }
+      if (bias) { a0 += *reinterpret_cast<const f32x4*>(bias + i); a1 += *reinterpret_cast<const f32x4*>(bias + i + 4); }
+      v0 += a0;
+      v1 += a1;
+      *reinterpret_cast<f32x4*>(hidden + (size_t)t * H + i) = v0;
+      *reinterpret_cast<f32x4*>(hidden + (size_t)t * H + i + 4) = v1;
     }
-    pf_row[i] = v;
-    ss = __builtin_fmaf(v, v, ss);
+    const f32x4 q = v0 * v0 + v1 * v1;
+    ss = (q.x + q.y) + (q.z + q.w);
+    if (xh) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { v[j] = v0[j] * w0[j]; v[4 + j] = v1[j] * w1[j]; }
+      xh_store_chunk(xh, t, ch, v);
+    }
   }
-  if (!xh) return;
   ss = wave_sum(ss);
   if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = ss;
   __syncthreads();
-  const float tot = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
-  const float inv = 1.0f / __builtin_sqrtf(tot / (float)H + eps);
-  for (uint32_t ch = threadIdx.x; ch < H / 8; ch += 256) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (pf_row[ch * 8 + j] * inv) * nw[ch * 8 + j];
-    xh_store_chunk(xh, t, ch, v);
-  }
+  if (threadIdx.x == 0 && ssq) ssq[t * kPfSsqChunks + blockIdx.x] = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
 }
 
+// chunks of per-token sums of squares a row of H elements is reduced to (pf_inv_rms adds them up)
+uint32_t pf_ssq_chunks(uint32_t H) { return (H + 2047) / 2048; }
+
 hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
-                             const float* nw, float eps, uint8_t* xh, uint32_t m_tokens, hipStream_t st) {
-  if (H % 8 || (xh && !nw)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_row_epi_kernel, dim3(m_tokens), dim3(256), (size_t)H * 4, st, part, S, ncols, col0, bias, hidden, H, nw, eps, xh);
+                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st) {
+  if (H % 8 || (xh && (!nw || !ssq)) || (S && (ncols % 4 || col0 % 4)) || pf_ssq_chunks(H) > (uint32_t)kPfSsqChunks) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_resid_kernel, dim3(pf_ssq_chunks(H), m_tokens), dim3(256), 0, st, part, S, ncols, col0, bias, hidden, H, nw, xh, ssq);
   return hipGetLastError();
 }
 
@@ -416,10 +446,12 @@ __global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict
                                                          uint32_t head_dim, const float* __restrict__ bq, const float* __restrict__ bk,
                                                          const float* __restrict__ bv, const float* __restrict__ rope_cs, uint32_t pos0,
                                                          uint32_t max_seq, float* __restrict__ qbuf, float* __restrict__ kcache,
-                                                         float* __restrict__ vcache) {
-  const uint32_t t = blockIdx.x, pos = pos0 + t, half = head_dim / 2;
+                                                         float* __restrict__ vcache, const float* __restrict__ ssq, uint32_t n_ssq,
+                                                         uint32_t H, float eps) {
+  const uint32_t t = blockIdx.y, pos = pos0 + t, half = head_dim / 2;
+  const float inv = pf_inv_rms(ssq, n_ssq, t, H, eps);
   const uint32_t npairs = (QD + 2 * KD) / 2;
-  for (uint32_t p = threadIdx.x; p < npairs; p += 256) {
+  for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < npairs; p += gridDim.x * 256) {
     const uint32_t col = 2 * p;
     float x0 = 0.0f, x1 = 0.0f;
     for (uint32_t s = 0; s < S; s++) {
@@ -427,6 +459,8 @@ __global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict
       x0 += v.x;
       x1 += v.y;
     }
+    x0 *= inv;
+    x1 *= inv;
     if (col < QD + KD) {
       const bool isq = col < QD;
       const uint32_t row = isq ? col : col - QD;
@@ -450,17 +484,19 @@ __global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict
 
 hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
                              const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
-                             float* kcache, float* vcache, uint32_t m_tokens, hipStream_t st) {
+                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, uint32_t m_tokens, hipStream_t st) {
   if (head_dim % 2 || ncols != QD + 2 * KD) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_qkv_epi_kernel, dim3(m_tokens), dim3(256), 0, st, part, S, ncols, QD, KD, head_dim, bq, bk, bv, rope_cs, pos0, max_seq,
-                     qbuf, kcache, vcache);
+  hipLaunchKernelGGL(pf_qkv_epi_kernel, dim3(((QD + 2 * KD) / 2 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, ncols, QD, KD, head_dim, bq, bk, bv, rope_cs, pos0, max_seq,
+                     qbuf, kcache, vcache, ssq, pf_ssq_chunks(H), H, eps);
   return hipGetLastError();
 }
 
 // act = silu(gate) * up (simd.rs:598-649) from the partial sums (gate in columns [0, F), up in [F, 2F)) -> XH[t][F]
-__global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict__ part, uint32_t S, uint32_t F, uint8_t* __restrict__ xh) {
+__global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict__ part, uint32_t S, uint32_t F, uint8_t* __restrict__ xh,
+                                                        const float* __restrict__ ssq, uint32_t n_ssq, uint32_t H, float eps) {
   const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
   if (ch >= F / 8) return;
+  const float inv = pf_inv_rms(ssq, n_ssq, t, H, eps);
   float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t s = 0; s < S; s++) {
     const float* row = part + ((size_t)s * kPfTokens + t) * (2 * (size_t)F);
@@ -471,13 +507,14 @@ __global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict_
   }
   float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; j++) v[j] = silu_f(g[j]) * u[j];
+  for (int j = 0; j < 8; j++) v[j] = silu_f(g[j] * inv) * (u[j] * inv);
   xh_store_chunk(xh, t, ch, v);
 }
 
-hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, uint32_t m_tokens, hipStream_t st) {
+hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, const float* ssq, uint32_t H, float eps, uint32_t m_tokens,
+                            hipStream_t st) {
   if (F % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_swiglu_kernel, dim3((F / 8 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, F, xh);
+  hipLaunchKernelGGL(pf_swiglu_kernel, dim3((F / 8 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, F, xh, ssq, pf_ssq_chunks(H), H, eps);
   return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ def _usage(src):
 
 
 def test_no_kernel_uses_scratch_or_spills_vgprs():
-    for src in ("matvec_mfma.hip", "attention.hip", "misc.hip", "dequant.hip"):
+    for src in ("matvec_mfma.hip", "prefill.hip", "attention.hip", "misc.hip", "dequant.hip"):
         usage = _usage(src)
         assert usage, f"no kernels found in {src}"
         for fn, u in usage.items():
@@ -44,3 +44,12 @@ def test_mfma_kernel_fits_two_waves_per_simd():
     assert len(mvq) == 7   # five formats + the Q4_K/Q6_K and Q5_K/Q6_K mixes
     for fn, u in mvq.items():
         assert u["VGPRs"] <= 256 and u.get("Occupancy", 2) >= 2, (fn, u)
+
+
+def test_prefill_gemm_keeps_its_accumulators_in_registers():
+    """128 f32 accumulators per lane (4 row tiles x 8 token tiles) live in the accumulation registers; one wave per SIMD."""
+    usage = _usage("prefill.hip")
+    gemm = {fn: u for fn, u in usage.items() if "pf_gemm_kernel" in fn}
+    assert len(gemm) == 8   # five formats, the Q4_K/Q6_K and Q5_K/Q6_K mixes, and the any-mix instantiation
+    for fn, u in gemm.items():
+        assert u.get("AGPRs", 0) >= 128 and u["VGPRs"] <= 256, (fn, u)
