@@ -42,6 +42,7 @@ def committed_traffic(kernel):
     return None, None
 
 
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 
 
@@ -178,9 +179,18 @@ def run_single(args, pkg):
         eng.forward_batch(prompt[:-1])
         eng.synchronize()
         bat_s = time.perf_counter() - t0
+        # multiply-adds the prompt pass performs: every layer's seven matrices, except that the last layer stops after
+        # its K/V projections (a prefill returns nothing; only the caches survive)
+        H, QD, KD, F, NL = cfg.hidden_size, cfg.num_heads * cfg.head_dim, cfg.num_kv_heads * cfg.head_dim, cfg.intermediate_size, cfg.num_layers
+        macs = (NL - 1) * (H * (QD + 2 * KD) + QD * H + 3 * H * F) + H * (QD + 2 * KD)
+        tflops = 2.0 * macs * (len(prompt) - 1) / bat_s / 1e12
         prefill = {"tokens": len(prompt) - 1, "batched": bool(eng.prefill_is_batched()),
                    "forward_batch_tokens_per_s": round((len(prompt) - 1) / bat_s, 1), "forward_batch_ms": round(1e3 * bat_s, 3),
-                   "token_by_token_tokens_per_s": round((len(prompt) - 1) / seq_s, 1)}
+                   "token_by_token_tokens_per_s": round((len(prompt) - 1) / seq_s, 1),
+                   "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4), "dtype": "f16 operands, f32 accumulation",
+                                "note": "whole prompt pass (GEMMs + attention + row kernels), dense models only"}
+                   if eng.prefill_is_batched() and not cfg.num_experts else None}
     eng.reset()
     eng.forward_batch(prompt[:-1])
     eng.forward(prompt[-1])
