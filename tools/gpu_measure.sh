@@ -29,6 +29,9 @@ rc=$?; echo "pmc fetch exit $rc"; [ $rc -ne 0 ] && { tail -5 "$R/$OUT/pmc_fetch.
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$R/$OUT/pmc_write" -o w --output-format csv -- \
   python3 "$R/bench.py" --steps 8 --warmup 2 --prompt 8 --cpu-seconds 0 --profile-steps 0 > /dev/null 2> "$R/$OUT/pmc_write.log"
 rc=$?; echo "pmc write exit $rc"; [ $rc -ne 0 ] && { tail -5 "$R/$OUT/pmc_write.log"; exit $rc; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$R/$OUT/prof_prefill" -o pf --output-format csv -- \
+  python3 "$R/tools/prefill_bench.py" > "$R/$OUT/prefill_bench.log" 2>&1
+rc=$?; echo "prefill prof exit $rc"; grep "tokens/s" "$R/$OUT/prefill_bench.log"
 cd "$R"
 # the trace itself is large; keep the stats and drop the per-dispatch rows beyond what the summary needs
 find "$OUT" -name '*kernel_trace.csv' -size +20M -delete

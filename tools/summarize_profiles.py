@@ -46,6 +46,9 @@ def main():
     dst.mkdir(exist_ok=True)
     stats = src / "prof" / "ktrace_kernel_stats.csv"
     shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
+    pf_stats = src / "prof_prefill" / "pf_kernel_stats.csv"     # the prompt pass alone (tools/prefill_bench.py)
+    if pf_stats.exists():
+        shutil.copy(pf_stats, dst / f"{tag}_prefill_kernel_stats.csv")
     bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
     (dst / f"{tag}_bench.json").write_text(json.dumps(bench) + "\n")
 
@@ -95,6 +98,19 @@ def main():
     if kname in traffic:
         lines.append(f"PMC traffic for it: {traffic[kname][5] / 1e6:.2f} MB/launch "
                      f"(FETCH_SIZE x2 + WRITE_SIZE; the PMC passes ran `bench.py --steps 8 --warmup 2 --prompt 8`).")
+    if bench.get("prefill"):
+        pf = bench["prefill"]
+        lines += ["", f"prompt pass ({pf['tokens']} tokens): lgh_prefill_batch {pf['forward_batch_ms']} ms = {pf['forward_batch_tokens_per_s']} tokens/s "
+                      f"(batched={pf['batched']}), token by token {pf['token_by_token_tokens_per_s']} tokens/s"
+                      + (f"; {pf['roofline']['achieved']} TFLOP/s = {pf['roofline']['frac']:.3f} of the {pf['roofline']['peak']} TFLOP/s dense f16 peak" if pf.get("roofline") else "")]
+        log = src / "prefill_bench.log"
+        if log.exists():
+            lines += [l.strip() for l in log.read_text().splitlines() if "tokens/s" in l]
+        if pf_stats.exists():
+            with open(pf_stats, newline="") as f:
+                rows_pf = [r for r in csv.DictReader(f) if "pf_" in r["Name"] or "attn_partial" in r["Name"] or "embed_batch" in r["Name"]]
+            lines += ["", "| prompt-pass kernel (6 passes of 128 tokens) | calls | avg us | share % |", "|---|---|---|---|"]
+            lines += [f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {r['Percentage']} |" for r in rows_pf]
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
     print("\n".join(lines))
 
