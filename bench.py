@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (0 disables)")
     ap.add_argument("--profile-steps", type=int, default=16, help="steps of the eager hipEvent pass (0 disables)")
     ap.add_argument("--attn-splits", type=int, default=0)
+    ap.add_argument("--attn-direct", type=int, default=0, help="single-launch decode attention up to 64*n rows (0 = default, 255 = never)")
     return ap.parse_args()
 
 
@@ -137,7 +138,7 @@ def run_single(args, pkg):
     want_cpu = args.cpu_seconds > 0
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
-    eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits)
+    eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct)
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
@@ -271,7 +272,7 @@ def run_pipeline(args, pkg):
     cfg = pkg.make_config(args.model, max_seq_len=max_seq)
     model = pkg.SynthModel(cfg, mix=args.mix)
     lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
-    eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits)
+    eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits, attn_direct=args.attn_direct)
     stage = pkg.pipeline.HipStage(eng, torch, dev)
     dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)

@@ -88,7 +88,9 @@ enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
   LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
   LGH_FLAG_EXACT_PREFILL = 1u << 2,  /* lgh_prefill_batch feeds the tokens one by one (f32 throughout) instead of the batched f16 GEMM path */
-  LGH_FLAG_ATTN_SPLITS_SHIFT = 8     /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
+  LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
+  LGH_FLAG_ATTN_DIRECT_SHIFT = 16    /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
+                                        per kv head, no split + combine pair); 0 = the tuned default, 255 = never */
 };
 
 typedef struct lgh_ctx lgh_ctx;

@@ -30,7 +30,10 @@ constexpr float kNegBig = -1e30f;
 // PF (prefill.hip): blockIdx.y = token t of a block of prompt tokens; it sees kv_len_fixed + t cache rows (causal), its
 // query is q + t * n_heads * D, there is one split, and the normalised output goes, as f16, into the XH matrix at
 // `part_acc` (prefill.h: the wo GEMM's input).
-template <int D, int G, int NW, bool PF = false>
+// DIRECT: one workgroup of NW = 16 waves per kv head and no second kernel: the workgroup merges its waves and writes the
+// normalised output (f32 at part_acc, XQ records at part_ml when not null) itself.  It saves one launch floor per layer
+// but pulls a kv head's whole K/V through one CU, so it only pays below ~100 rows (engine.hip: kDirectAttnDefaultKv).
+template <int D, int G, int NW, bool PF = false, bool DIRECT = false>
 __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
                                                            const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
@@ -147,7 +150,11 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
       lsum += s_ml[w][g][1] * f;
       a += s_acc[w][g][dim] * f;
     }
-    if (PF) {
+    if (DIRECT) {
+      const float o = a * (1.0f / lsum);   // simd.rs:718-720: multiply by 1/sum
+      part_acc[(pbase + g) * D + dim] = o;
+      if (part_ml) xq_store_chunk(reinterpret_cast<uint8_t*>(part_ml), (uint32_t)((pbase + g) * D + dim) >> 4, o);   // wo's input as XQ records
+    } else if (PF) {
       const _Float16 o = (_Float16)(a * (1.0f / lsum));   // simd.rs:718-720: multiply by 1/sum
       *reinterpret_cast<_Float16*>(reinterpret_cast<uint8_t*>(part_acc) + xh_offset(blockIdx.y, (uint32_t)(pbase + g) * D + dim)) = o;
     } else {
@@ -217,6 +224,27 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
 #define LGH_ATTN_CASE(DD, GG) \
   if (head_dim == DD && g == GG)  \
     return attn_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, kv_len_fixed, n_splits, part_ml, part_acc, st);
+  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
+  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
+#undef LGH_ATTN_CASE
+  return hipErrorInvalidValue;
+}
+
+template <int D, int G>
+static hipError_t attn_direct_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale, const int* pos,
+                                 float* out, uint8_t* xq_out, hipStream_t st) {
+  hipLaunchKernelGGL((attn_partial_kernel<D, G, 16, false, true>), dim3(n_kv), dim3(1024), 0, st, q, kc, vc, max_seq, scale, pos, 0, 1u,
+                     reinterpret_cast<float*>(xq_out), out);
+  return hipGetLastError();
+}
+
+// single-launch decode attention for short contexts (engine.hip picks it by the host-side position)
+hipError_t attn_direct_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                              uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || !pos) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_ATTN_CASE(DD, GG) \
+  if (head_dim == DD && g == GG) return attn_direct_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, out, xq_out, st);
   LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
   LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
 #undef LGH_ATTN_CASE

@@ -197,6 +197,8 @@ hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, con
 hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
                        uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, int kv_len_fixed,
                        uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
+hipError_t attn_direct_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                              uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st);
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
 

@@ -68,7 +68,9 @@ struct lgh_ctx {
   bool finalized = false;
   bool profiling = false;
   std::string err;
-  hipGraphExec_t graph[lgh::MODE_COUNT] = {nullptr, nullptr, nullptr};
+  hipGraphExec_t graph[lgh::MODE_COUNT][2] = {};   // [mode][attention variant: 0 split + combine, 1 single launch (short context)]
+  bool attn_direct = false;                        // variant of the token being enqueued (chosen by the host-side position)
+  uint32_t direct_attn_max_kv = 0;                 // contexts up to this many rows take the single-launch attention
   uint64_t graph_nodes = 0;
   // accounting
   lgh_stats stats{};

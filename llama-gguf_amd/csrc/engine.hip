@@ -60,6 +60,11 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
   (void)hipFree(p);
 }
 
+// Contexts up to this many rows run the single-launch decode attention (attention.hip, DIRECT) unless the flags say
+// otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
+// 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
+constexpr uint32_t kDirectAttnDefaultKv = 64;
+
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,20 +474,31 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   // ---- attention_cached (ops.rs:1479-1537)
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
-  if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
-         return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
-                            c->state + ST_POS, 0, c->n_splits, c->part_ml, c->part_acc, c->stream);
-       })))
-    return rc;
-  {
-    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;   // wo's input as XQ, straight from the merge
-    if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
-           return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out,
-                                      qa ? qa->xq : nullptr, c->stream);
+  if (c->attn_direct) {
+    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_direct_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
+                                     c->state + ST_POS, c->attn_out, qa ? qa->xq : nullptr, c->stream);
          })))
       return rc;
     if (qa) { qa->fresh = true; qa->tag = nullptr; }
     else xq_stale(c, c->attn_out);
+  } else {
+  if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
+                              c->state + ST_POS, 0, c->n_splits, c->part_ml, c->part_acc, c->stream);
+         })))
+      return rc;
+    {
+      XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;   // wo's input as XQ, straight from the merge
+      if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
+             return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out,
+                                        qa ? qa->xq : nullptr, c->stream);
+           })))
+        return rc;
+      if (qa) { qa->fresh = true; qa->tag = nullptr; }
+      else xq_stale(c, c->attn_out);
+    }
   }
   // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
   const bool ffn_mfma = Lw.moe() ? mfma_type(Lw.gate_exps.type) : mfma_type(Lw.gate.type);
@@ -613,7 +629,8 @@ static int enqueue_token(lgh_ctx* c, int mode) {
 }
 
 static int ensure_graph(lgh_ctx* c, int mode) {
-  if (c->graph[mode]) return LGH_OK;
+  const int var = c->attn_direct ? 1 : 0;
+  if (c->graph[mode][var]) return LGH_OK;
   hipGraph_t g = nullptr;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   c->chain_pending.clear();
@@ -633,7 +650,7 @@ static int ensure_graph(lgh_ctx* c, int mode) {
   size_t n_nodes = 0;
   (void)hipGraphGetNodes(g, nullptr, &n_nodes);
   if (mode == MODE_GREEDY || c->graph_nodes == 0) c->graph_nodes = n_nodes;
-  e = hipGraphInstantiate(&c->graph[mode], g, nullptr, nullptr, 0);
+  e = hipGraphInstantiate(&c->graph[mode][var], g, nullptr, nullptr, 0);
   (void)hipGraphDestroy(g);
   if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
   return LGH_OK;
@@ -644,12 +661,13 @@ static int step(lgh_ctx* c, int mode) {
   if (c->pos >= c->d.max_seq_len)  // the reference has no such check: OOB write past the KV capacity
     return fail(c, LGH_INVALID_ARGUMENT, "position " + std::to_string(c->pos) + " >= max_seq_len " + std::to_string(c->d.max_seq_len));
   int rc;
+  c->attn_direct = c->pos + 1 <= c->direct_attn_max_kv;   // the token at position pos attends to pos + 1 rows
   if (c->profiling || (c->d.flags & LGH_FLAG_NO_GRAPH)) {
     if ((rc = enqueue_token(c, mode))) return rc;
     if (c->profiling && (rc = drain_prof(c))) return rc;
   } else {
     if ((rc = ensure_graph(c, mode))) return rc;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode], c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode][c->attn_direct ? 1 : 0], c->stream));
   }
   c->pos += 1;
   c->stats.tokens_processed += 1;
@@ -807,6 +825,8 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   }
   if (splits > 32) splits = 32;   // the split merge keeps one partial per split in registers
   c->n_splits = splits;
+  const uint32_t dsel = (d.flags >> LGH_FLAG_ATTN_DIRECT_SHIFT) & 0xFFu;
+  c->direct_attn_max_kv = dsel == 255 ? 0 : dsel ? dsel * 64 : kDirectAttnDefaultKv;
   *out = c;
   return LGH_OK;
 }
@@ -1017,7 +1037,8 @@ void lgh_destroy(lgh_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int m = 0; m < MODE_COUNT; m++)
-    if (c->graph[m]) (void)hipGraphExecDestroy(c->graph[m]);
+    for (int v = 0; v < 2; v++)
+      if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1161,7 +1182,8 @@ int lgh_set_stream(lgh_ctx* c, void* s) {
   hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
   if (ns != c->stream) {
     for (int m = 0; m < MODE_COUNT; m++)
-      if (c->graph[m]) { (void)hipGraphExecDestroy(c->graph[m]); c->graph[m] = nullptr; }
+      for (int v = 0; v < 2; v++)
+        if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
   }
   c->stream = ns;
   return LGH_OK;

@@ -151,7 +151,7 @@ class HipGpuInference:
     # -- pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>  (gpu_only.rs:426)
     @classmethod
     def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
-                   flags: int = 0, attn_splits: int = 0) -> "HipGpuInference":
+                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0) -> "HipGpuInference":
         """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
         `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
         L = load_library()
@@ -170,7 +170,7 @@ class HipGpuInference:
         d.layer_begin, d.layer_end = lb, le
         if os.environ.get("LGH_CHAIN_FFN", "") not in ("", "0"):
             flags |= FLAG_CHAIN_FFN
-        d.flags = flags | ((attn_splits & 0xFF) << 8)
+        d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16)   # attn_direct: 64-row units, 255 = never
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
         try:

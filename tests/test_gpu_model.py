@@ -277,3 +277,28 @@ def test_chained_ffn_launch_matches_separate_launches(pkg, orc, name, mix):
     finally:
         a.close()
         b.close()
+
+
+def test_single_launch_and_split_attention_agree_across_the_switch(pkg, orc):
+    """Decode attention runs as one launch per layer up to a context threshold and as split + combine beyond it (two
+    graph variants, picked by the host-side position).  One engine switches at 64 rows in mid-sequence, one never uses
+    the single launch, one always does; all three must follow the oracle."""
+    cfg = pkg.make_config("test-dense-d128", max_seq_len=160)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    engs = [pkg.HipGpuInference.from_model(model, 160, flags=pkg.hip_backend.FLAG_EXACT_PREFILL, attn_direct=a) for a in (1, 255, 4)]
+    toks = [(13 * i + 5) % cfg.vocab_size for i in range(100)]
+    worst = 0.0
+    for i, t in enumerate(toks):
+        want = ref.forward([t])
+        got = [e.forward(t) for e in engs]
+        if i in (0, 31, 62, 63, 64, 65, 99):            # around the switch at 64 rows, and the ends
+            for g in got:
+                worst = max(worst, float(np.abs(g - want).max()))
+                assert np.abs(g - want).max() <= _tol(want)
+    print(f"max|dlogit| over the three attention variants: {worst:.3e}")
+    for e in engs:
+        e.close()
