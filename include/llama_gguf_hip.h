@@ -236,6 +236,33 @@ int lgh_op_attention_cached(int device, const float* q, const float* k_cache, co
                             size_t kv_len, int n_splits);
 /* simd::silu_mul_inplace: out = silu(gate) * up */
 int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, size_t n);
+/* The rest of the per-op `Backend` trait (src/backend/mod.rs:29-265; CPU: src/backend/cpu/ops.rs), host tensors in and out,
+ * for `select_gpu_backend` (src/engine.rs:738-812).  add / mul / scale (ops.rs:24-300) and matmul (row-major [m,k] @ [k,n],
+ * ops.rs:429-528) are bit-exact with the CPU backend; silu / gelu / softmax (ops.rs:303-385, softmax along the last
+ * dimension of [rows, last_dim]) differ by the device exp / tanh only; matvec ([m,k] @ [k], ops.rs:531-570) and matvec_q
+ * (ops.rs:922-950) read the same bytes as vec_mat / vec_mat_q with n = m; attention is the causal GQA attention of
+ * ops.rs:1353-1472 (q, out [heads, seq, d]; k, v [kv_heads, kv_len, d]). */
+int lgh_op_add(int device, const float* a, const float* b, float* out, size_t n);
+int lgh_op_mul(int device, const float* a, const float* b, float* out, size_t n);
+int lgh_op_scale(int device, const float* a, float scalar, float* out, size_t n);
+int lgh_op_silu(int device, const float* x, float* out, size_t n);
+int lgh_op_gelu(int device, const float* x, float* out, size_t n);
+int lgh_op_softmax(int device, const float* x, float* out, size_t rows, size_t last_dim);
+int lgh_op_matmul(int device, const float* a, const float* b, float* out, size_t m, size_t k, size_t n);
+int lgh_op_matvec(int device, const float* a, const float* x, float* out, size_t m, size_t k);
+int lgh_op_matvec_q(int device, uint32_t ggml_type, const void* a, const float* x, float* out, size_t m, size_t k);
+int lgh_op_attention(int device, const float* q, const float* k, const float* v, float* out, size_t n_heads, size_t n_kv_heads,
+                     size_t seq_len, size_t kv_len, size_t head_dim, float scale);
+/* Device-resident weights by tensor name for the per-op surface: `CudaBackend::load_model_weights` and the `b.name()`
+ * lookups in its vec_mat / vec_mat_q (src/backend/cuda/mod.rs:121-146, 436-470, 511-575).  A weight is uploaded once
+ * (native GGUF bytes; the library re-lays it out as lgh_upload_tensor does) and later calls name it. */
+typedef struct lgh_backend lgh_backend;
+int lgh_backend_create(int device, lgh_backend** out);
+void lgh_backend_destroy(lgh_backend* be);
+int lgh_backend_load_weight(lgh_backend* be, const char* name, uint32_t ggml_type, const void* w, size_t k, size_t n);
+int lgh_backend_has_weight(const lgh_backend* be, const char* name);
+int lgh_backend_vec_mat_q(lgh_backend* be, const char* name, const float* x, float* out, size_t k, size_t n);
+const char* lgh_backend_last_error(const lgh_backend* be);
 /* fused decode kernels, for kernel-level parity: out = resid + W.(rms_norm(x)*norm_w) etc. */
 int lgh_op_norm_vec_mat(int device, uint32_t ggml_type, const void* w, const float* x, const float* norm_w, float eps,
                         float* out, size_t k, size_t n);

@@ -272,6 +272,57 @@ hipError_t attn_prefill_launch(const float* q, const float* kcache, const float*
   return hipErrorInvalidValue;
 }
 
+// Backend::attention for any head_dim / group size (per-op surface only; the engine's shapes take the kernels above):
+// one workgroup per (head, query position), scores in LDS, the arithmetic of ops.rs:1353-1472 — sequential dot per score,
+// max, exp, sum, weights times 1/sum, then V accumulated in position order.
+__global__ void __launch_bounds__(256) attn_generic_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           float* __restrict__ out, uint32_t per_kv, uint32_t seq_len, uint32_t kv_len,
+                                                           uint32_t kv_rows, uint32_t d, float scale) {
+  extern __shared__ float sc[];
+  __shared__ float s_red[4];
+  const uint32_t head = blockIdx.x, s = blockIdx.y, kvh = head / per_kv;
+  const uint32_t q_abs = (kv_len >= seq_len ? kv_len - seq_len : 0) + s;
+  const uint32_t visible = q_abs + 1 < kv_len ? q_abs + 1 : kv_len;
+  const float* qv = q + ((size_t)head * seq_len + s) * d;
+  const float* kb = k + (size_t)kvh * kv_rows * d;   // kv_rows: rows per kv head in memory (a cache: max_seq_len)
+  const float* vb = v + (size_t)kvh * kv_rows * d;
+  float m = -INFINITY;
+  for (uint32_t p = threadIdx.x; p < visible; p += 256) {
+    float dot = 0.0f;
+    for (uint32_t i = 0; i < d; i++) dot += qv[i] * kb[(size_t)p * d + i];
+    sc[p] = dot * scale;
+    m = fmaxf(m, sc[p]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (uint32_t p = threadIdx.x; p < visible; p += 256) {
+    const float e = expf(sc[p] - m);
+    sc[p] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  for (uint32_t i = threadIdx.x; i < d; i += 256) {
+    float o = 0.0f;
+    for (uint32_t p = 0; p < visible; p++) o += (sc[p] * inv) * vb[(size_t)p * d + i];
+    out[((size_t)head * seq_len + s) * d + i] = o;
+  }
+}
+
+hipError_t attn_generic_launch(const float* q, const float* k, const float* v, float* out, uint32_t n_heads, uint32_t n_kv, uint32_t seq_len,
+                               uint32_t kv_len, uint32_t kv_rows, uint32_t d, float scale, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || seq_len == 0 || kv_len == 0 || kv_len > 16000 || kv_rows < kv_len || seq_len > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_generic_kernel, dim3(n_heads, seq_len), dim3(256), (size_t)kv_len * 4, st, q, k, v, out, n_heads / n_kv, seq_len,
+                     kv_len, kv_rows, d, scale);
+  return hipGetLastError();
+}
+
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || head_dim % 16 || head_dim > 128 || n_splits > 32) return hipErrorInvalidValue;

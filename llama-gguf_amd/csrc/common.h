@@ -186,6 +186,10 @@ hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, fl
 hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st);
 hipError_t rope_launch(float* q, float* k, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, const int* pos,
                        const float* rope_cs, int neox, hipStream_t st);
+// the rest of the per-op Backend surface (misc.hip): op = 0 add, 1 mul, 2 scale, 3 silu, 4 gelu
+hipError_t ewise_launch(int op, const float* a, const float* b, float s, float* out, uint64_t n, hipStream_t st);
+hipError_t softmax_rows_launch(const float* x, float* out, uint32_t rows, uint32_t last_dim, hipStream_t st);
+hipError_t matmul_f32_launch(const float* a, const float* b, float* c, uint32_t m, uint32_t k, uint32_t n, hipStream_t st);
 hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint32_t n, hipStream_t st);
 hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,
                          hipStream_t st);
@@ -199,6 +203,8 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
                        uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
 hipError_t attn_direct_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
                               uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st);
+hipError_t attn_generic_launch(const float* q, const float* k, const float* v, float* out, uint32_t n_heads, uint32_t n_kv, uint32_t seq_len,
+                               uint32_t kv_len, uint32_t kv_rows, uint32_t d, float scale, hipStream_t st);
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
 

@@ -73,6 +73,97 @@ hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint3
 }
 
 // ---------------------------------------------------------------------------------------------
+// The element-wise / activation / softmax / f32 matmul ops of the reference's per-op `Backend` trait
+// (src/backend/mod.rs:29-265; CPU: src/backend/cpu/ops.rs:24-528).  Not on the decode path: they complete the
+// trait surface for `select_gpu_backend` (src/engine.rs:738-812).  add / mul / scale and the f32 matmul (ascending k, one
+// rounding per step, no contraction) are bit-exact with the CPU backend.
+// ---------------------------------------------------------------------------------------------
+enum { EW_ADD = 0, EW_MUL = 1, EW_SCALE = 2, EW_SILU = 3, EW_GELU = 4 };
+
+template <int OP>
+__global__ void __launch_bounds__(256) ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, float s,
+                                                    float* __restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const float x = a[i];
+    float r;
+    if (OP == EW_ADD) r = x + b[i];                                   // ops.rs:24-116
+    else if (OP == EW_MUL) r = x * b[i];                              // ops.rs:119-208
+    else if (OP == EW_SCALE) r = x * s;                               // ops.rs:211-300
+    else if (OP == EW_SILU) r = x / (1.0f + expf(-x));                // ops.rs:303-325
+    else {                                                            // ops.rs:328-347
+      const float inner = 0.7978846f * (x + 0.044715f * x * x * x);
+      r = 0.5f * x * (1.0f + tanhf(inner));
+    }
+    out[i] = r;
+  }
+}
+
+hipError_t ewise_launch(int op, const float* a, const float* b, float s, float* out, uint64_t n, hipStream_t st) {
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (blocks == 0) return hipSuccess;
+  const dim3 g((uint32_t)blocks), t(256);
+  switch (op) {
+    case EW_ADD: hipLaunchKernelGGL(ewise_kernel<EW_ADD>, g, t, 0, st, a, b, s, out, n); break;
+    case EW_MUL: hipLaunchKernelGGL(ewise_kernel<EW_MUL>, g, t, 0, st, a, b, s, out, n); break;
+    case EW_SCALE: hipLaunchKernelGGL(ewise_kernel<EW_SCALE>, g, t, 0, st, a, b, s, out, n); break;
+    case EW_SILU: hipLaunchKernelGGL(ewise_kernel<EW_SILU>, g, t, 0, st, a, b, s, out, n); break;
+    case EW_GELU: hipLaunchKernelGGL(ewise_kernel<EW_GELU>, g, t, 0, st, a, b, s, out, n); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// softmax along the last dimension, one workgroup per row (ops.rs:350-385: max, exp(x - max), sum, times 1/sum)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ out, uint32_t last_dim) {
+  __shared__ float s_red[4];
+  const float* row = x + (size_t)blockIdx.x * last_dim;
+  float* orow = out + (size_t)blockIdx.x * last_dim;
+  float m = -INFINITY;
+  for (uint32_t i = threadIdx.x; i < last_dim; i += 256) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (uint32_t i = threadIdx.x; i < last_dim; i += 256) {
+    const float e = expf(row[i] - m);
+    orow[i] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  for (uint32_t i = threadIdx.x; i < last_dim; i += 256) orow[i] *= inv;
+}
+
+hipError_t softmax_rows_launch(const float* x, float* out, uint32_t rows, uint32_t last_dim, hipStream_t st) {
+  if (rows == 0 || last_dim == 0) return hipSuccess;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, st, x, out, last_dim);
+  return hipGetLastError();
+}
+
+// row-major [m,k] @ [k,n] (ops.rs:429-528): one thread per output element, products added in ascending k exactly as both
+// CPU variants do (the tiled one continues the same running sum across its k-chunks) -> bit-identical results
+__global__ void __launch_bounds__(256) matmul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ c,
+                                                         uint32_t m, uint32_t k, uint32_t n) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= n) return;
+  float sum = 0.0f;
+  for (uint32_t kk = 0; kk < k; kk++) sum += a[(size_t)i * k + kk] * b[(size_t)kk * n + j];
+  c[(size_t)i * n + j] = sum;
+}
+
+hipError_t matmul_f32_launch(const float* a, const float* b, float* c, uint32_t m, uint32_t k, uint32_t n, hipStream_t st) {
+  if (m == 0 || n == 0) return hipSuccess;
+  if (m > 65535) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(matmul_f32_kernel, dim3((n + 255) / 256, m), dim3(256), 0, st, a, b, c, m, k, n);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Arg-max with the reference's tie rule: Iterator::max_by returns the LAST maximal element
 // (src/main.rs:1815-1821).  Stage 1: 64 workgroups -> partials; stage 2: one workgroup -> state.
 // ---------------------------------------------------------------------------------------------

@@ -195,6 +195,12 @@ int lgh_op_attention_cached(int device, const float* q, const float* kc, const f
   float *dq = t.up(q, n_heads * d), *dk = t.up(kc, cache), *dv = t.up(vc, cache), *dout = t.up(nullptr, n_heads * d);
   float *pml = t.up(nullptr, n_kv * n_splits * g * 2), *pacc = t.up(nullptr, n_kv * n_splits * g * d);
   if (!dq || !dk || !dv || !dout || !pml || !pacc) return LGH_ALLOCATION_FAILED;
+  if (!((d == 64 || d == 128) && (g == 1 || g == 2 || g == 4 || g == 8))) {   // shapes outside the engine's kernels
+    if (attn_generic_launch(dq, dk, dv, dout, (uint32_t)n_heads, (uint32_t)n_kv, 1, (uint32_t)kv_len, (uint32_t)max_seq, (uint32_t)d, scale,
+                            t.c->stream) != hipSuccess)
+      return LGH_UNSUPPORTED;
+    return t.down(out, dout, n_heads * d);
+  }
   if (attn_launch(dq, dk, dv, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)max_seq, scale, nullptr, (int)kv_len,
                   (uint32_t)n_splits, pml, pacc, t.c->stream) != hipSuccess)
     return LGH_UNSUPPORTED;
@@ -211,6 +217,155 @@ int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, 
   if (silu_mul_launch(dg, du, dout, (uint32_t)n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
   return t.down(out, dout, n);
 }
+
+// ---- Backend::add / mul / scale / silu / gelu / softmax / matmul / matvec / matvec_q / attention (backend/mod.rs:29-265) ----
+static int ewise_impl(int device, int op, const float* a, const float* b, float s, float* out, size_t n) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (n == 0) return LGH_OK;
+  if (!a || !out || ((op == 0 || op == 1) && !b)) return LGH_INVALID_ARGUMENT;
+  float *da = t.up(a, n), *db = b ? t.up(b, n) : nullptr, *dout = t.up(nullptr, n);
+  if (!da || !dout || (b && !db)) return LGH_ALLOCATION_FAILED;
+  if (ewise_launch(op, da, db, s, dout, n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, n);
+}
+int lgh_op_add(int device, const float* a, const float* b, float* out, size_t n) { return ewise_impl(device, 0, a, b, 0.0f, out, n); }
+int lgh_op_mul(int device, const float* a, const float* b, float* out, size_t n) { return ewise_impl(device, 1, a, b, 0.0f, out, n); }
+int lgh_op_scale(int device, const float* a, float scalar, float* out, size_t n) { return ewise_impl(device, 2, a, nullptr, scalar, out, n); }
+int lgh_op_silu(int device, const float* x, float* out, size_t n) { return ewise_impl(device, 3, x, nullptr, 0.0f, out, n); }
+int lgh_op_gelu(int device, const float* x, float* out, size_t n) { return ewise_impl(device, 4, x, nullptr, 0.0f, out, n); }
+
+int lgh_op_softmax(int device, const float* x, float* out, size_t rows, size_t last_dim) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (rows * last_dim == 0) return LGH_OK;
+  if (!x || !out || rows > 0x7FFFFFFFu || last_dim > 0xFFFFFFFFu) return LGH_INVALID_ARGUMENT;
+  float *dx = t.up(x, rows * last_dim), *dout = t.up(nullptr, rows * last_dim);
+  if (!dx || !dout) return LGH_ALLOCATION_FAILED;
+  if (softmax_rows_launch(dx, dout, (uint32_t)rows, (uint32_t)last_dim, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, rows * last_dim);
+}
+
+int lgh_op_matmul(int device, const float* a, const float* b, float* out, size_t m, size_t k, size_t n) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!a || !b || !out || m == 0 || n == 0 || m > 65535) return LGH_INVALID_ARGUMENT;
+  float *da = t.up(a, m * k), *db = t.up(b, k * n), *dout = t.up(nullptr, m * n);
+  if (!da || !db || !dout) return LGH_ALLOCATION_FAILED;
+  if (matmul_f32_launch(da, db, dout, (uint32_t)m, (uint32_t)k, (uint32_t)n, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  return t.down(out, dout, m * n);
+}
+
+int lgh_op_matvec(int device, const float* a, const float* x, float* out, size_t m, size_t k) {
+  // [m,k] row-major times [k]: the memory layout of vec_mat's GGUF-order weight with n = m (ops.rs:531-570 vs 959-1002)
+  return vec_mat_impl(device, LGH_TYPE_F32, a, nullptr, x, nullptr, 1e-5f, nullptr, out, k, m);
+}
+
+int lgh_op_matvec_q(int device, uint32_t type, const void* a, const float* x, float* out, size_t m, size_t k) {
+  // quantized rows of k elements, m of them: the same bytes vec_mat_q reads (ops.rs:922-950 vs 1008-1039)
+  return vec_mat_impl(device, type, a, nullptr, x, nullptr, 1e-5f, nullptr, out, k, m);
+}
+
+int lgh_op_attention(int device, const float* q, const float* k, const float* v, float* out, size_t n_heads, size_t n_kv, size_t seq_len,
+                     size_t kv_len, size_t d, float scale) {
+  // q / out [heads, seq, d], k / v [kv_heads, kv_len, d]; query s sits at position kv_len - seq_len + s and sees the
+  // rows up to itself (ops.rs:1353-1472).  One split-attention pass per query position over the SAME kernels the engine
+  // runs: k / v are a cache with max_seq = kv_len.
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!q || !k || !v || !out || n_kv == 0 || n_heads % n_kv || seq_len == 0 || kv_len == 0) return LGH_INVALID_ARGUMENT;
+  const size_t g = n_heads / n_kv, cache = n_kv * kv_len * d;
+  const int n_splits = 8;
+  float *dq = t.up(q, n_heads * seq_len * d), *dk = t.up(k, cache), *dv = t.up(v, cache), *dout = t.up(nullptr, n_heads * seq_len * d);
+  float *qs = t.up(nullptr, n_heads * d), *os = t.up(nullptr, n_heads * d);
+  float *pml = t.up(nullptr, n_kv * n_splits * g * 2), *pacc = t.up(nullptr, n_kv * n_splits * g * d);
+  if (!dq || !dk || !dv || !dout || !qs || !os || !pml || !pacc) return LGH_ALLOCATION_FAILED;
+  hipStream_t st = t.c->stream;
+  const bool fast = (d == 64 || d == 128) && (g == 1 || g == 2 || g == 4 || g == 8);
+  if (!fast) {   // shapes outside the engine's kernels: the generic kernel
+    if (attn_generic_launch(dq, dk, dv, dout, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)seq_len, (uint32_t)kv_len, (uint32_t)kv_len, (uint32_t)d, scale, st) != hipSuccess)
+      return LGH_UNSUPPORTED;
+    return t.down(out, dout, n_heads * seq_len * d);
+  }
+  for (size_t s = 0; s < seq_len; s++) {
+    const size_t q_abs = (kv_len >= seq_len ? kv_len - seq_len : 0) + s;   // saturating_sub (ops.rs:1411)
+    const size_t visible = q_abs + 1 < kv_len ? q_abs + 1 : kv_len;
+    if (hipMemcpy2DAsync(qs, d * 4, dq + s * d, seq_len * d * 4, d * 4, n_heads, hipMemcpyDeviceToDevice, st) != hipSuccess) return LGH_OPERATION_FAILED;
+    if (attn_launch(qs, dk, dv, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)kv_len, scale, nullptr, (int)visible,
+                    (uint32_t)n_splits, pml, pacc, st) != hipSuccess)
+      return LGH_UNSUPPORTED;
+    if (attn_combine_launch(pml, pacc, (uint32_t)n_heads, (uint32_t)n_kv, (uint32_t)d, (uint32_t)n_splits, os, nullptr, st) != hipSuccess)
+      return LGH_OPERATION_FAILED;
+    if (hipMemcpy2DAsync(dout + s * d, seq_len * d * 4, os, d * 4, d * 4, n_heads, hipMemcpyDeviceToDevice, st) != hipSuccess) return LGH_OPERATION_FAILED;
+  }
+  return t.down(out, dout, n_heads * seq_len * d);
+}
+
+// ---- device-resident weights by tensor name: CudaBackend::load_model_weights + the `b.name()` lookups of its vec_mat /
+// vec_mat_q (src/backend/cuda/mod.rs:121-146, 436-470, 511-575; store: cuda/dequant_weights.rs) ----
+}  // extern "C"
+
+#include <map>
+#include <memory>
+#include <string>
+
+struct lgh_backend {
+  std::unique_ptr<Tmp> t;
+  std::map<std::string, DevWeight> weights;
+  float *x = nullptr, *out = nullptr;   // staging, grown on demand
+  size_t x_cap = 0, out_cap = 0;
+  uint64_t hits = 0;
+};
+
+extern "C" {
+
+int lgh_backend_create(int device, lgh_backend** out) {
+  if (!out) return LGH_INVALID_ARGUMENT;
+  *out = nullptr;
+  auto be = std::make_unique<lgh_backend>();
+  be->t = std::make_unique<Tmp>(device);
+  if (be->t->rc) return be->t->rc;
+  *out = be.release();
+  return LGH_OK;
+}
+
+void lgh_backend_destroy(lgh_backend* be) { delete be; }
+
+int lgh_backend_load_weight(lgh_backend* be, const char* name, uint32_t type, const void* w, size_t k, size_t n) {
+  if (!be || !name || !w) return LGH_INVALID_ARGUMENT;
+  lgh_ctx* c = be->t->c;
+  if (hipSetDevice(c->device) != hipSuccess) return LGH_NOT_AVAILABLE;
+  const uint32_t bs = blk_elems((int)type);
+  if (!bs || k % bs) return LGH_SHAPE_MISMATCH;
+  if (be->weights.count(name)) return fail(c, LGH_INVALID_ARGUMENT, std::string("weight already loaded: ") + name);
+  DevWeight W;
+  int rc = upload_matrix(c, W, (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, n * (k / bs) * blk_bytes((int)type));
+  if (rc) return rc;
+  be->weights.emplace(name, W);
+  return LGH_OK;
+}
+
+int lgh_backend_has_weight(const lgh_backend* be, const char* name) { return be && name && be->weights.count(name) ? 1 : 0; }
+
+int lgh_backend_vec_mat_q(lgh_backend* be, const char* name, const float* x, float* out, size_t k, size_t n) {
+  if (!be || !name || !x || !out) return LGH_INVALID_ARGUMENT;
+  lgh_ctx* c = be->t->c;
+  if (hipSetDevice(c->device) != hipSuccess) return LGH_NOT_AVAILABLE;
+  auto it = be->weights.find(name);
+  if (it == be->weights.end()) return fail(c, LGH_INVALID_ARGUMENT, std::string("no device-resident weight named ") + name);
+  const DevWeight& W = it->second;
+  if (W.k != k || W.n != n) return fail(c, LGH_SHAPE_MISMATCH, std::string(name) + ": vec_mat_q dimension mismatch");   // cuda/mod.rs:528-534
+  if (k > be->x_cap) { if (dev_alloc(c, (void**)&be->x, k * 4)) return LGH_ALLOCATION_FAILED; be->x_cap = k; }
+  if (n > be->out_cap) { if (dev_alloc(c, (void**)&be->out, n * 4)) return LGH_ALLOCATION_FAILED; be->out_cap = n; }
+  if (hipMemcpyAsync(be->x, x, k * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  xq_stale(c, be->x);
+  int rc = linear_any(c, LGH_K_MISC, W, be->x, be->out, nullptr, nullptr, nullptr);
+  if (rc) return rc;
+  be->hits++;
+  return be->t->down(out, be->out, n);
+}
+
+const char* lgh_backend_last_error(const lgh_backend* be) { return be ? be->t->c->err.c_str() : "null backend"; }
 
 int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, size_t k, size_t n, int mode, int iters,
                       int copies, double* avg_us) {

@@ -23,7 +23,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip%s.so" % ("_" + os.envir
 # every symbol include/llama_gguf_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "lgh_device_count", "lgh_create", "lgh_upload_tensor", "lgh_finalize", "lgh_destroy", "lgh_forward",
-    "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
+    "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat",
+    "lgh_op_add", "lgh_op_mul", "lgh_op_scale", "lgh_op_silu", "lgh_op_gelu", "lgh_op_softmax", "lgh_op_matmul", "lgh_op_matvec",
+    "lgh_op_matvec_q", "lgh_op_attention", "lgh_backend_create", "lgh_backend_destroy", "lgh_backend_load_weight",
+    "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
@@ -115,6 +118,15 @@ def load_library() -> C.CDLL:
         "lgh_op_silu_mul": (C.c_int, [C.c_int, vp, vp, vp, sz]),
         "lgh_op_norm_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
+        "lgh_op_add": (C.c_int, [C.c_int, vp, vp, vp, sz]), "lgh_op_mul": (C.c_int, [C.c_int, vp, vp, vp, sz]),
+        "lgh_op_scale": (C.c_int, [C.c_int, vp, f32, vp, sz]), "lgh_op_silu": (C.c_int, [C.c_int, vp, vp, sz]),
+        "lgh_op_gelu": (C.c_int, [C.c_int, vp, vp, sz]), "lgh_op_softmax": (C.c_int, [C.c_int, vp, vp, sz, sz]),
+        "lgh_op_matmul": (C.c_int, [C.c_int, vp, vp, vp, sz, sz, sz]), "lgh_op_matvec": (C.c_int, [C.c_int, vp, vp, vp, sz, sz]),
+        "lgh_op_matvec_q": (C.c_int, [C.c_int, u32, vp, vp, vp, sz, sz]),
+        "lgh_op_attention": (C.c_int, [C.c_int, vp, vp, vp, vp, sz, sz, sz, sz, sz, f32]),
+        "lgh_backend_create": (C.c_int, [C.c_int, C.POINTER(vp)]), "lgh_backend_destroy": (None, [vp]),
+        "lgh_backend_load_weight": (C.c_int, [vp, C.c_char_p, u32, vp, sz, sz]), "lgh_backend_has_weight": (C.c_int, [vp, C.c_char_p]),
+        "lgh_backend_vec_mat_q": (C.c_int, [vp, C.c_char_p, vp, vp, sz, sz]), "lgh_backend_last_error": (C.c_char_p, [vp]),
         "lgh_bench_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, sz, sz, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
         "lgh_bench_hbm_read": (C.c_int, [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]),
         "lgh_gguf_inspect": (C.c_int, [C.c_char_p, C.POINTER(GgufInfo), C.c_char_p, sz]),
@@ -398,6 +410,152 @@ def op_silu_mul(gate, up, device: int = 0) -> np.ndarray:
     out = np.empty_like(g)
     _chk(load_library().lgh_op_silu_mul(device, g.ctypes.data, u.ctypes.data, out.ctypes.data, g.size), "silu_mul")
     return out
+
+
+class HipBackend:
+    """Mirror of the reference's per-op `Backend` trait (src/backend/mod.rs:29-265) over the C ABI: host tensors (numpy
+    arrays) in and out, the same method names and argument meaning; what `select_gpu_backend` (src/engine.rs:738-812) would
+    hold as `Box<dyn Backend>`.  `load_weight` + a `name=` on vec_mat_q is the CUDA backend's device-resident weight store
+    (src/backend/cuda/mod.rs:121-146, 511-575).  No CPU fallback: every method runs a HIP kernel or raises."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self._h = C.c_void_p()
+        _chk(load_library().lgh_backend_create(device, C.byref(self._h)), "lgh_backend_create (is a HIP device visible?)")
+
+    def close(self) -> None:
+        if self._h:
+            load_library().lgh_backend_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def name(self) -> str:
+        return "hip"
+
+    def is_available(self) -> bool:
+        return device_count() > self.device
+
+    # memory: host tensors are the currency of this surface (backend/mod.rs:40-49)
+    def alloc(self, shape, dtype=np.float32) -> np.ndarray:
+        return np.zeros(shape, dtype=dtype)
+
+    def copy_to(self, tensor: np.ndarray) -> np.ndarray:
+        return np.array(tensor, copy=True)
+
+    def _ew(self, fn, what, *arrs, scalar=None):
+        a = [_f32(x) for x in arrs]
+        for b in a[1:]:
+            if b.shape != a[0].shape:
+                raise BackendError(2, f"{what}: shapes {a[0].shape} and {b.shape} differ")   # check_same_shape (ops.rs:1543)
+        out = np.empty_like(a[0])
+        args = [self.device] + [x.ctypes.data for x in a] + ([scalar] if scalar is not None else []) + [out.ctypes.data, out.size]
+        _chk(fn(*args), what)
+        return out
+
+    def add(self, a, b) -> np.ndarray:
+        return self._ew(load_library().lgh_op_add, "add", a, b)
+
+    def mul(self, a, b) -> np.ndarray:
+        return self._ew(load_library().lgh_op_mul, "mul", a, b)
+
+    def scale(self, a, scalar: float) -> np.ndarray:
+        return self._ew(load_library().lgh_op_scale, "scale", a, scalar=float(scalar))
+
+    def silu(self, x) -> np.ndarray:
+        return self._ew(load_library().lgh_op_silu, "silu", x)
+
+    def gelu(self, x) -> np.ndarray:
+        return self._ew(load_library().lgh_op_gelu, "gelu", x)
+
+    def softmax(self, x) -> np.ndarray:
+        x = _f32(x)
+        out = np.empty_like(x)
+        last = x.shape[-1] if x.ndim else 1
+        _chk(load_library().lgh_op_softmax(self.device, x.ctypes.data, out.ctypes.data, x.size // max(last, 1), last), "softmax")
+        return out
+
+    def rms_norm(self, x, weight, eps: float) -> np.ndarray:
+        return op_rms_norm(x, weight, eps, self.device)
+
+    def matmul(self, a, b) -> np.ndarray:
+        a, b = _f32(a), _f32(b)
+        if a.ndim != 2 or b.ndim != 2:
+            raise BackendError(6, "matmul requires 2D tensors")                                  # ops.rs:434-438
+        if a.shape[1] != b.shape[0]:
+            raise BackendError(2, f"matmul: [{a.shape}] @ [{b.shape}]")                            # ops.rs:443-448
+        out = np.empty((a.shape[0], b.shape[1]), dtype=np.float32)
+        _chk(load_library().lgh_op_matmul(self.device, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.shape[0], a.shape[1], b.shape[1]), "matmul")
+        return out
+
+    def matvec(self, a, b) -> np.ndarray:
+        a, b = _f32(a), _f32(b)
+        if a.ndim != 2 or b.ndim != 1:
+            raise BackendError(6, "matvec requires 2D matrix and 1D vector")                     # ops.rs:536-540
+        if b.shape[0] != a.shape[1]:
+            raise BackendError(2, f"matvec: expected [{a.shape[1]}], got {b.shape}")
+        out = np.empty(a.shape[0], dtype=np.float32)
+        _chk(load_library().lgh_op_matvec(self.device, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.shape[0], a.shape[1]), "matvec")
+        return out
+
+    def vec_mat(self, a, b_f32, n: int) -> np.ndarray:
+        """x [k] @ W [k, n] with W in GGUF order (element (i, j) at i + j*k, ops.rs:959-1002)."""
+        return op_vec_mat(0, _f32(b_f32), a, n, self.device)
+
+    def dequantize(self, ggml_type: int, raw: np.ndarray, n_elems: int) -> np.ndarray:
+        return op_dequantize(ggml_type, raw, n_elems, self.device)
+
+    def matvec_q(self, ggml_type: int, a_raw: np.ndarray, b, m: int) -> np.ndarray:
+        a_raw, b = np.ascontiguousarray(a_raw), _f32(b)
+        out = np.empty(m, dtype=np.float32)
+        _chk(load_library().lgh_op_matvec_q(self.device, ggml_type, a_raw.ctypes.data, b.ctypes.data, out.ctypes.data, m, b.size), "matvec_q")
+        return out
+
+    def load_weight(self, name: str, ggml_type: int, raw: np.ndarray, k: int, n: int) -> None:
+        raw = np.ascontiguousarray(raw)
+        self._call(load_library().lgh_backend_load_weight(self._h, name.encode(), ggml_type, raw.ctypes.data, k, n))
+
+    def has_weight(self, name: str) -> bool:
+        return bool(load_library().lgh_backend_has_weight(self._h, name.encode()))
+
+    def vec_mat_q(self, a, ggml_type: int = 0, b_raw: Optional[np.ndarray] = None, n: int = 0, name: Optional[str] = None) -> np.ndarray:
+        """x [k] @ quantized W (n rows of k/bs blocks).  With `name` of a loaded weight nothing but x crosses PCIe."""
+        a = _f32(a)
+        if name is not None and self.has_weight(name):
+            out = np.empty(n, dtype=np.float32)
+            self._call(load_library().lgh_backend_vec_mat_q(self._h, name.encode(), a.ctypes.data, out.ctypes.data, a.size, n))
+            return out
+        if b_raw is None:
+            raise BackendError(6, f"vec_mat_q: no device-resident weight named {name!r} and no host tensor given")
+        return op_vec_mat(ggml_type, b_raw, a, n, self.device)
+
+    def rope(self, q, k, pos: int, freq_base: float, freq_scale: float, use_neox: bool):
+        return op_rope(q, k, pos, freq_base, freq_scale, use_neox, self.device)
+
+    def attention(self, q, k, v, scale: float) -> np.ndarray:
+        q, k, v = _f32(q), _f32(k), _f32(v)
+        if q.ndim != 3 or k.ndim != 3 or v.ndim != 3:
+            raise BackendError(6, "Attention requires 3D tensors")                               # ops.rs:1365-1369
+        if k.shape[2] != q.shape[2] or v.shape != k.shape or q.shape[0] % k.shape[0]:
+            raise BackendError(6, "Attention tensor dimension mismatch")                         # ops.rs:1381-1389
+        out = np.empty_like(q)
+        _chk(load_library().lgh_op_attention(self.device, q.ctypes.data, k.ctypes.data, v.ctypes.data, out.ctypes.data, q.shape[0],
+                                             k.shape[0], q.shape[1], k.shape[1], q.shape[2], scale), "attention")
+        return out
+
+    def flash_attention(self, q, k, v, scale: float, causal: bool = True) -> np.ndarray:   # backend/mod.rs:159-171: defaults to attention
+        return self.attention(q, k, v, scale)
+
+    def attention_cached(self, q, k_cache, v_cache, scale: float, kv_len: int) -> np.ndarray:
+        return op_attention_cached(q, k_cache, v_cache, scale, kv_len, device=self.device)
+
+    def _call(self, status: int) -> None:
+        if status != 0:
+            raise BackendError(status, load_library().lgh_backend_last_error(self._h).decode())
 
 
 def bench_vec_mat(ggml_type: int, w: np.ndarray, k: int, n: int, mode: int = 0, iters: int = 50,

@@ -309,6 +309,80 @@ void orc_attention_cached(const float* q, const float* k_cache, const float* v_c
   });
 }
 
+// ---- the rest of the per-op `Backend` surface (src/backend/mod.rs:29-265), CPU implementations in ops.rs ----
+void orc_add(const float* a, const float* b, float* out, size_t n) {  // ops.rs:24-116: out = a + b, one rounding per element
+  for (size_t i = 0; i < n; i++) out[i] = a[i] + b[i];
+}
+void orc_mul(const float* a, const float* b, float* out, size_t n) {  // ops.rs:119-208
+  for (size_t i = 0; i < n; i++) out[i] = a[i] * b[i];
+}
+void orc_scale(const float* a, float s, float* out, size_t n) {  // ops.rs:211-300
+  for (size_t i = 0; i < n; i++) out[i] = a[i] * s;
+}
+void orc_gelu(const float* x, float* out, size_t n) {  // ops.rs:328-347: tanh approximation, f32 throughout
+  const float kSqrt2OverPi = 0.7978846f;
+  for (size_t i = 0; i < n; i++) {
+    float v = x[i];
+    float inner = kSqrt2OverPi * (v + 0.044715f * v * v * v);
+    out[i] = 0.5f * v * (1.0f + std::tanh(inner));
+  }
+}
+void orc_softmax_rows(const float* x, float* out, size_t rows, size_t last_dim) {  // ops.rs:350-385: along the last dimension
+  for (size_t r = 0; r < rows; r++) {
+    for (size_t i = 0; i < last_dim; i++) out[r * last_dim + i] = x[r * last_dim + i];
+    orc_softmax_inplace(out + r * last_dim, last_dim);
+  }
+}
+void orc_matmul(const float* a, const float* b, float* c, size_t m, size_t k, size_t n) {
+  // ops.rs:429-528: row-major [m,k] @ [k,n]; both variants (simple / tiled in k-chunks of 32 that continue the same
+  // running sum) add the products of one output element in ascending k, one f32 rounding per step
+  orc_parallel_for(m, 1, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++)
+      for (size_t j = 0; j < n; j++) {
+        float sum = 0.0f;
+        for (size_t kk = 0; kk < k; kk++) sum += a[i * k + kk] * b[kk * n + j];
+        c[i * n + j] = sum;
+      }
+  });
+}
+void orc_matvec(const float* a, const float* x, float* out, size_t m, size_t k) {  // ops.rs:531-570: dot_f32 per row
+  orc_parallel_for(m, 8, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; i++) out[i] = orc_dot_f32(a + i * k, x, k);
+  });
+}
+void orc_attention(const float* q, const float* k, const float* v, float* out, size_t n_heads, size_t n_kv_heads, size_t seq_len,
+                   size_t kv_len, size_t head_dim, float scale) {  // ops.rs:1353-1472: causal, GQA, scalar loops
+  size_t per_kv = n_heads / n_kv_heads;
+  std::vector<float> scores(kv_len);
+  for (size_t head = 0; head < n_heads; head++) {
+    size_t kvh = head / per_kv;
+    for (size_t s = 0; s < seq_len; s++) {
+      const float* qv = q + (head * seq_len + s) * head_dim;
+      size_t q_abs = (kv_len >= seq_len ? kv_len - seq_len : 0) + s;   // saturating_sub (ops.rs:1411)
+      for (size_t p = 0; p < kv_len; p++) {
+        if (p > q_abs) { scores[p] = -std::numeric_limits<float>::infinity(); continue; }
+        const float* kv = k + (kvh * kv_len + p) * head_dim;
+        float dot = 0.0f;
+        for (size_t d = 0; d < head_dim; d++) dot += qv[d] * kv[d];
+        scores[p] = dot * scale;
+      }
+      float mx = -std::numeric_limits<float>::infinity();
+      for (size_t p = 0; p < kv_len; p++) mx = std::fmax(mx, scores[p]);   // fold(NEG_INFINITY, f32::max)
+      float sum = 0.0f;
+      for (size_t p = 0; p < kv_len; p++) { scores[p] = std::exp(scores[p] - mx); sum += scores[p]; }
+      float inv = 1.0f / sum;
+      for (size_t p = 0; p < kv_len; p++) scores[p] *= inv;
+      float* o = out + (head * seq_len + s) * head_dim;
+      for (size_t d = 0; d < head_dim; d++) o[d] = 0.0f;
+      for (size_t p = 0; p < kv_len; p++)
+        if (scores[p] > 0.0f) {
+          const float* vv = v + (kvh * kv_len + p) * head_dim;
+          for (size_t d = 0; d < head_dim; d++) o[d] += scores[p] * vv[d];
+        }
+    }
+  }
+}
+
 void orc_vec_mat_f32(const float* w, const float* x, float* out, size_t k, size_t n) {  // ops.rs:959-1002
   orc_parallel_for(n, 16, [&](size_t j0, size_t j1) {
     for (size_t j = j0; j < j1; j++) {

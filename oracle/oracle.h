@@ -68,6 +68,16 @@ void orc_attention_cached(const float* q, const float* k_cache, const float* v_c
                           size_t n_heads, size_t n_kv_heads, size_t head_dim, size_t max_seq_len,
                           float scale, size_t kv_len);
 void orc_softmax_inplace(float* x, size_t n);
+/* per-op Backend surface (src/backend/mod.rs:29-265; CPU: ops.rs) */
+void orc_add(const float* a, const float* b, float* out, size_t n);
+void orc_mul(const float* a, const float* b, float* out, size_t n);
+void orc_scale(const float* a, float s, float* out, size_t n);
+void orc_gelu(const float* x, float* out, size_t n);
+void orc_softmax_rows(const float* x, float* out, size_t rows, size_t last_dim);
+void orc_matmul(const float* a, const float* b, float* c, size_t m, size_t k, size_t n);
+void orc_matvec(const float* a, const float* x, float* out, size_t m, size_t k);
+void orc_attention(const float* q, const float* k, const float* v, float* out, size_t n_heads, size_t n_kv_heads, size_t seq_len,
+                   size_t kv_len, size_t head_dim, float scale);
 void orc_silu(const float* x, float* out, size_t n);
 void orc_silu_mul_inplace(float* gate, const float* up, size_t n);
 float orc_max_f32(const float* x, size_t n);

@@ -66,6 +66,10 @@ def lib() -> C.CDLL:
         "orc_rope": (None, [vp, vp, sz, sz, sz, sz, sz, C.c_float, C.c_float, C.c_int]),
         "orc_attention_cached": (None, [vp, vp, vp, vp, sz, sz, sz, sz, C.c_float, sz]),
         "orc_softmax_inplace": (None, [vp, sz]), "orc_silu": (None, [vp, vp, sz]),
+        "orc_add": (None, [vp, vp, vp, sz]), "orc_mul": (None, [vp, vp, vp, sz]), "orc_scale": (None, [vp, C.c_float, vp, sz]),
+        "orc_gelu": (None, [vp, vp, sz]), "orc_softmax_rows": (None, [vp, vp, sz, sz]),
+        "orc_matmul": (None, [vp, vp, vp, sz, sz, sz]), "orc_matvec": (None, [vp, vp, vp, sz, sz]),
+        "orc_attention": (None, [vp, vp, vp, vp, sz, sz, sz, sz, sz, C.c_float]),
         "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]),
         "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
@@ -187,6 +191,65 @@ def softmax(x) -> np.ndarray:
     x = _f32(x).copy()
     lib().orc_softmax_inplace(_p(x), x.size)
     return x
+
+
+def add(a, b) -> np.ndarray:
+    a, b = _f32(a), _f32(b)
+    out = np.empty_like(a)
+    lib().orc_add(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def mul(a, b) -> np.ndarray:
+    a, b = _f32(a), _f32(b)
+    out = np.empty_like(a)
+    lib().orc_mul(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def scale(a, s: float) -> np.ndarray:
+    a = _f32(a)
+    out = np.empty_like(a)
+    lib().orc_scale(_p(a), s, _p(out), a.size)
+    return out
+
+
+def gelu(x) -> np.ndarray:
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_gelu(_p(x), _p(out), x.size)
+    return out
+
+
+def softmax_rows(x) -> np.ndarray:
+    """Backend::softmax: along the last dimension (ops.rs:350-385)."""
+    x = _f32(x)
+    out = np.empty_like(x)
+    last = x.shape[-1] if x.ndim else 1
+    lib().orc_softmax_rows(_p(x), _p(out), x.size // max(last, 1), last)
+    return out
+
+
+def matmul(a, b) -> np.ndarray:
+    a, b = _f32(a), _f32(b)
+    out = np.empty((a.shape[0], b.shape[1]), dtype=np.float32)
+    lib().orc_matmul(_p(a), _p(b), _p(out), a.shape[0], a.shape[1], b.shape[1])
+    return out
+
+
+def matvec(a, x) -> np.ndarray:
+    a, x = _f32(a), _f32(x)
+    out = np.empty(a.shape[0], dtype=np.float32)
+    lib().orc_matvec(_p(a), _p(x), _p(out), a.shape[0], a.shape[1])
+    return out
+
+
+def attention(q, k, v, scale_: float) -> np.ndarray:
+    """Backend::attention: q [heads, seq, d], k / v [kv_heads, kv_len, d], causal (ops.rs:1353-1472)."""
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    out = np.empty_like(q)
+    lib().orc_attention(_p(q), _p(k), _p(v), _p(out), q.shape[0], k.shape[0], q.shape[1], k.shape[1], q.shape[2], scale_)
+    return out
 
 
 def silu(x) -> np.ndarray:

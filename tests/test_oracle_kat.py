@@ -193,3 +193,45 @@ def test_vec_mat_q_matches_rowwise_dots_and_fallback(orc):
             row = raw[j * rb:(j + 1) * rb]
             want = orc.dot_q(t, row, x) if orc.lib().orc_has_fused_dot(t) else orc.dot_f32(x, orc.dequantize(t, row, k))
             assert out[j] == np.float32(want)
+
+
+def test_backend_trait_elementwise_kats(orc):
+    """ops.rs:1567-1630: test_add, test_mul, test_scale (exact), test_silu, test_softmax."""
+    assert np.array_equal(orc.add([1, 2, 3, 4], [10, 20, 30, 40]), np.float32([11, 22, 33, 44]))
+    assert np.array_equal(orc.mul([1, 2, 3, 4], [2, 3, 4, 5]), np.float32([2, 6, 12, 20]))
+    assert np.array_equal(orc.scale([1, 2, 3, 4], 2.5), np.float32([2.5, 5.0, 7.5, 10.0]))
+    s = orc.silu([0.0, 1.0, -1.0, 2.0])
+    assert abs(s[0]) < 1e-6 and abs(s[1] - 0.731) < 0.01 and abs(s[2] + 0.269) < 0.01
+    p = orc.softmax_rows([1.0, 2.0, 3.0, 4.0])
+    assert abs(float(p.sum()) - 1.0) < 1e-6 and p[0] < p[1] < p[2] < p[3]
+    rows = orc.softmax_rows(np.arange(12, dtype=np.float32).reshape(3, 4))       # along the last dimension
+    assert np.allclose(rows.sum(axis=1), 1.0, atol=1e-6) and np.array_equal(rows[0], rows[1])
+    g = orc.gelu([0.0, 1.0, -1.0, 3.0])                                           # ops.rs:328-347: tanh approximation
+    assert g[0] == 0.0 and abs(g[1] - 0.8412) < 1e-3 and abs(g[2] + 0.1588) < 1e-3 and abs(g[3] - 2.9964) < 1e-3
+
+
+def test_backend_trait_matmul_matvec_kats(orc):
+    """ops.rs:1651-1680: test_matmul ([[22, 28], [49, 64]]) and test_matvec ([30, 70, 110]), both exact."""
+    a, b = np.float32([[1, 2, 3], [4, 5, 6]]), np.float32([[1, 2], [3, 4], [5, 6]])
+    assert np.array_equal(orc.matmul(a, b), np.float32([[22, 28], [49, 64]]))
+    assert np.array_equal(orc.matvec(np.arange(1, 13, dtype=np.float32).reshape(3, 4), [1, 2, 3, 4]), np.float32([30, 70, 110]))
+    rng = np.random.default_rng(1)                                               # large enough for the tiled variant (m*k*n >= 256^3)
+    a, b = rng.standard_normal((300, 260)).astype(np.float32), rng.standard_normal((260, 280)).astype(np.float32)
+    assert np.allclose(orc.matmul(a, b), a.astype(np.float64) @ b.astype(np.float64), atol=2e-4)
+
+
+def test_backend_trait_attention_kats(orc):
+    """ops.rs:1779-1810: test_attention_simple (position 0 sees only itself) and test_attention_gqa."""
+    q = np.float32([1, 0, 0, 0, 0, 1, 0, 0]).reshape(1, 2, 4)
+    v = np.float32([1, 2, 3, 4, 5, 6, 7, 8]).reshape(1, 2, 4)
+    out = orc.attention(q, q.copy(), v, 1.0 / np.sqrt(2.0))
+    assert np.array_equal(out[0, 0], v[0, 0])                                    # causal: a softmax over one element
+    assert np.all(out[0, 1] > v[0, 0]) and np.all(out[0, 1] < v[0, 1])           # a proper mixture at position 1
+    ones = orc.attention(np.ones((4, 1, 4), np.float32), np.ones((2, 1, 4), np.float32), np.ones((2, 1, 4), np.float32), 0.5)
+    assert np.all(np.isfinite(ones)) and np.array_equal(ones, np.ones((4, 1, 4), np.float32))
+    # the cached form on the same data agrees (ops.rs:1479-1537 vs 1353-1472): last query position of a 5-row context
+    rng = np.random.default_rng(2)
+    qq, kk, vv = (rng.standard_normal(s).astype(np.float32) for s in ((4, 3, 8), (2, 5, 8), (2, 5, 8)))
+    full = orc.attention(qq, kk, vv, 0.35)
+    cached = orc.attention_cached(qq[:, 2, :], kk, vv, 0.35, 5)
+    assert np.allclose(full[:, 2, :], cached, atol=1e-6)
