@@ -307,6 +307,7 @@ int lgh_op_attention(int device, const float* q, const float* k, const float* v,
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 
 struct lgh_backend {
@@ -315,6 +316,7 @@ struct lgh_backend {
   float *x = nullptr, *out = nullptr;   // staging, grown on demand
   size_t x_cap = 0, out_cap = 0;
   uint64_t hits = 0;
+  std::mutex mu;   // `Backend: Send + Sync` (backend/mod.rs:29): calls on one handle may come from several threads
 };
 
 extern "C" {
@@ -333,6 +335,7 @@ void lgh_backend_destroy(lgh_backend* be) { delete be; }
 
 int lgh_backend_load_weight(lgh_backend* be, const char* name, uint32_t type, const void* w, size_t k, size_t n) {
   if (!be || !name || !w) return LGH_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(be->mu);
   lgh_ctx* c = be->t->c;
   if (hipSetDevice(c->device) != hipSuccess) return LGH_NOT_AVAILABLE;
   const uint32_t bs = blk_elems((int)type);
@@ -345,10 +348,15 @@ int lgh_backend_load_weight(lgh_backend* be, const char* name, uint32_t type, co
   return LGH_OK;
 }
 
-int lgh_backend_has_weight(const lgh_backend* be, const char* name) { return be && name && be->weights.count(name) ? 1 : 0; }
+int lgh_backend_has_weight(const lgh_backend* be, const char* name) {
+  if (!be || !name) return 0;
+  std::lock_guard<std::mutex> lock(const_cast<lgh_backend*>(be)->mu);
+  return be->weights.count(name) ? 1 : 0;
+}
 
 int lgh_backend_vec_mat_q(lgh_backend* be, const char* name, const float* x, float* out, size_t k, size_t n) {
   if (!be || !name || !x || !out) return LGH_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(be->mu);
   lgh_ctx* c = be->t->c;
   if (hipSetDevice(c->device) != hipSuccess) return LGH_NOT_AVAILABLE;
   auto it = be->weights.find(name);
