@@ -188,6 +188,13 @@ int lgh_prefill_is_batched(lgh_ctx* ctx);
 void lgh_reset(lgh_ctx* ctx);
 /* GpuInference::position (gpu_only.rs:845-847) */
 size_t lgh_position(const lgh_ctx* ctx);
+/* KVCache::truncate (src/model/mod.rs:130-134): forget the rows from new_len on (no-op when new_len >= position). */
+int lgh_kv_truncate(lgh_ctx* ctx, size_t new_len);
+/* KVCache::shift_left (src/model/mod.rs:142-172) on the DEVICE cache, with the position following as ChatEngine does
+ * (src/engine.rs:1394-1411: the reference shifts its host-side cache only, so a GPU engine keeps the untrimmed rows).
+ * Rows [amount, position) move to the front; amount == 0 or >= position clears the cache, as in the reference.  The rows
+ * keep the RoPE rotation of their old positions (the reference does not re-rotate either). */
+int lgh_kv_shift_left(lgh_ctx* ctx, size_t amount);
 
 /* forward + the bench's arg-max (src/main.rs:1812-1822; ties -> LAST maximal index) on device:
  * only 4 bytes cross PCIe. */

@@ -81,6 +81,7 @@ struct lgh_ctx {
   std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
   unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
   lgh::PfScratch pf;
+  float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 
 // ---- helpers shared by engine.hip and ops_api.hip ----

@@ -1103,6 +1103,40 @@ void lgh_reset(lgh_ctx* c) {
 
 size_t lgh_position(const lgh_ctx* c) { return c ? c->pos : 0; }
 
+int lgh_kv_truncate(lgh_ctx* c, size_t new_len) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (new_len < c->pos) {   // KVCache::truncate (model/mod.rs:130-134): only ever shortens
+    c->pos = new_len;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), (int)c->pos, 1, c->stream));
+  }
+  return LGH_OK;
+}
+
+int lgh_kv_shift_left(lgh_ctx* c, size_t amount) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  const lgh_model_desc& d = c->d;
+  if (amount == 0 || amount >= c->pos) {   // model/mod.rs:143-146 — a shift by 0 clears the cache too
+    c->pos = 0;
+  } else {
+    // rows [amount, pos) of every kv head move to [0, pos - amount) (model/mod.rs:148-169).  The ranges overlap, so each
+    // tensor goes through a scratch buffer: two strided device-to-device copies instead of the host's memmove.
+    const size_t new_len = c->pos - amount, row = (size_t)d.head_dim * 4;
+    if (!c->kv_shift_tmp && (rc = dev_alloc(c, (void**)&c->kv_shift_tmp, (size_t)d.num_kv_heads * d.max_seq_len * row))) return rc;
+    for (uint32_t li = c->l0; li < c->l1; li++)
+      for (float* cache : {c->layers[li].kcache, c->layers[li].vcache}) {
+        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(c->kv_shift_tmp, new_len * row, cache + amount * d.head_dim, (size_t)d.max_seq_len * row,
+                                                          new_len * row, d.num_kv_heads, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(cache, (size_t)d.max_seq_len * row, c->kv_shift_tmp, new_len * row, new_len * row,
+                                                          d.num_kv_heads, hipMemcpyDeviceToDevice, c->stream));
+      }
+    c->pos = new_len;
+  }
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), (int)c->pos, 1, c->stream));
+  return LGH_OK;
+}
+
 int lgh_forward_argmax(lgh_ctx* c, uint32_t token, uint32_t* next_token) {
   int rc = check_ready(c);
   if (rc) return rc;

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat",
     "lgh_op_add", "lgh_op_mul", "lgh_op_scale", "lgh_op_silu", "lgh_op_gelu", "lgh_op_softmax", "lgh_op_matmul", "lgh_op_matvec",
     "lgh_op_matvec_q", "lgh_op_attention", "lgh_backend_create", "lgh_backend_destroy", "lgh_backend_load_weight",
-    "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_forward_argmax", "lgh_decode_greedy",
+    "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_kv_truncate", "lgh_kv_shift_left", "lgh_forward_argmax", "lgh_decode_greedy",
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
         "lgh_forward": (C.c_int, [vp, u32, vp]), "lgh_prefill_token": (C.c_int, [vp, u32]),
         "lgh_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_prefill_is_batched": (C.c_int, [vp]),
         "lgh_op_mat_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, sz, sz, sz]), "lgh_reset": (None, [vp]), "lgh_position": (sz, [vp]),
+        "lgh_kv_truncate": (C.c_int, [vp, sz]), "lgh_kv_shift_left": (C.c_int, [vp, sz]),
         "lgh_forward_argmax": (C.c_int, [vp, u32, C.POINTER(u32)]),
         "lgh_decode_greedy": (C.c_int, [vp, u32, sz, vp]),
         "lgh_last_error": (C.c_char_p, [vp]), "lgh_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
@@ -242,6 +243,12 @@ class HipGpuInference:
 
     def position(self) -> int:
         return load_library().lgh_position(self._h)
+
+    def kv_truncate(self, new_len: int) -> None:       # KVCache::truncate (model/mod.rs:130-134)
+        self._call(load_library().lgh_kv_truncate(self._h, new_len))
+
+    def kv_shift_left(self, amount: int) -> None:      # KVCache::shift_left (model/mod.rs:142-172) on the device cache
+        self._call(load_library().lgh_kv_shift_left(self._h, amount))
 
     # -- bench fast paths
     def forward_argmax(self, token_id: int) -> int:

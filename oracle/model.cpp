@@ -299,6 +299,22 @@ int orc_model_finalize(orc_model* m) {
 void orc_model_reset(orc_model* m) { m->position = 0; }  // KVCache::reset (model/mod.rs:110-117): O(1)
 size_t orc_model_position(const orc_model* m) { return m->position; }
 
+void orc_model_kv_truncate(orc_model* m, size_t new_len) {  // KVCache::truncate (model/mod.rs:130-134)
+  if (new_len < m->position) m->position = new_len;
+}
+
+void orc_model_kv_shift_left(orc_model* m, size_t amount) {  // KVCache::shift_left (model/mod.rs:142-172) + engine.rs:1407-1408
+  // NB: a shift by 0 CLEARS the cache, exactly as a shift by >= seq_len does (model/mod.rs:143-146)
+  if (amount == 0 || amount >= m->position) { m->position = 0; return; }
+  const orc_config& c = m->cfg;
+  size_t new_len = m->position - amount, row_stride = (size_t)c.max_seq_len * c.head_dim, n = new_len * c.head_dim;
+  for (size_t li = 0; li < m->k_cache.size(); li++)
+    for (auto* cache : {&m->k_cache[li], &m->v_cache[li]})
+      for (size_t h = 0; h < c.num_kv_heads; h++)
+        std::memmove(cache->data() + h * row_stride, cache->data() + h * row_stride + amount * c.head_dim, n * sizeof(float));
+  m->position = new_len;   // the rows keep the RoPE rotation of their OLD positions (the reference does not re-rotate)
+}
+
 int orc_model_forward(orc_model* m, const uint32_t* tokens, size_t n_tokens, float* logits, int faithful_embedding) {
   if (!m->finalized) return fail(m, "forward before finalize");
   const orc_config& c = m->cfg;

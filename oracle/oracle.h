@@ -119,6 +119,9 @@ int orc_model_forward(orc_model* m, const uint32_t* tokens, size_t n_tokens, flo
                       int faithful_embedding);
 void orc_model_reset(orc_model* m);
 size_t orc_model_position(const orc_model* m);
+/* KVCache::truncate / shift_left (model/mod.rs:130-172); the position follows the cache (engine.rs:1407-1408) */
+void orc_model_kv_truncate(orc_model* m, size_t new_len);
+void orc_model_kv_shift_left(orc_model* m, size_t amount);
 /* debug taps: hidden state after the last forward's final layer (pre-norm) */
 int orc_model_last_hidden(const orc_model* m, float* out);
 

@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         "orc_model_finalize": (C.c_int, [vp]), "orc_model_last_error": (C.c_char_p, [vp]),
         "orc_model_forward": (C.c_int, [vp, vp, sz, vp, C.c_int]),
         "orc_model_reset": (None, [vp]), "orc_model_position": (sz, [vp]),
+        "orc_model_kv_truncate": (None, [vp, sz]), "orc_model_kv_shift_left": (None, [vp, sz]),
         "orc_model_last_hidden": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -321,6 +322,12 @@ class Model:
 
     def reset(self) -> None:
         lib().orc_model_reset(self._h)
+
+    def kv_truncate(self, new_len: int) -> None:
+        lib().orc_model_kv_truncate(self._h, new_len)
+
+    def kv_shift_left(self, amount: int) -> None:
+        lib().orc_model_kv_shift_left(self._h, amount)
 
     @property
     def position(self) -> int:

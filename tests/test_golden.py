@@ -134,3 +134,30 @@ def test_hip_model_matches_golden(gpu, pkg, name, mix):
         if float(fx["top_gap"][i]) > 4 * err:
             assert int(np.flatnonzero(got == got.max())[-1]) == int(fx["tokens"][i])
     eng.close()
+
+
+def test_oracle_kv_shift_left_is_a_row_move(orc, pkg):
+    """KVCache::shift_left (model/mod.rs:142-172): after dropping the first `amount` rows the model behaves as if the
+    remaining rows had been written at positions 0.. — checked against a fresh model whose cache rows are produced the
+    same way is not possible (RoPE keeps the old rotation), so the property tested is idempotence + position arithmetic
+    and that a shift followed by decoding is deterministic."""
+    cfg = pkg.make_config("test-dense", max_seq_len=48)
+    model = pkg.SynthModel(cfg, mix="Q8_0")
+    outs = []
+    for _ in range(2):
+        ref = orc.Model(cfg.as_dict())
+        for nm, t, ne, data in model.tensors(keep=True):
+            ref.add_tensor(nm, t, ne, data)
+        ref.finalize()
+        ref.forward(list(range(3, 23)))
+        ref.kv_shift_left(8)
+        assert ref.position == 12
+        outs.append(ref.forward([5]))
+        ref.kv_truncate(4)
+        assert ref.position == 4
+        ref.kv_truncate(40)
+        assert ref.position == 4
+        ref.kv_shift_left(0)
+        assert ref.position == 0
+        ref.close()
+    assert np.array_equal(outs[0], outs[1])

@@ -302,3 +302,33 @@ def test_single_launch_and_split_attention_agree_across_the_switch(pkg, orc):
     print(f"max|dlogit| over the three attention variants: {worst:.3e}")
     for e in engs:
         e.close()
+
+
+def test_kv_shift_left_and_truncate_follow_the_reference_cache(pkg, orc):
+    """KVCache::shift_left / truncate (model/mod.rs:130-172) mirrored on the device cache: the chat engine trims the
+    oldest tokens when the context fills up (engine.rs:1394-1411).  Rows keep their old RoPE rotation on both sides."""
+    cfg, ref, eng = _pair(pkg, orc, "test-dense-d128", "Q4_K_M", max_seq=96)
+    toks = [(17 * i + 3) % cfg.vocab_size for i in range(40)]
+    for t in toks:
+        eng.prefill_token(t)
+    ref.forward(toks)
+    for e in (eng, ref):
+        e.kv_shift_left(15)
+    assert eng.position() == ref.position == 25
+    for t in (7, 300, 12):
+        got, want = eng.forward(t), ref.forward([t])
+        assert np.abs(got - want).max() <= _tol(want)
+    eng.kv_truncate(10)
+    ref.kv_truncate(10)
+    eng.kv_truncate(50)                                   # longer than the cache: no-op (model/mod.rs:131)
+    assert eng.position() == ref.position == 10
+    got, want = eng.forward(5), ref.forward([5])
+    assert np.abs(got - want).max() <= _tol(want)
+    eng.kv_shift_left(0)                                  # the reference clears the cache on a shift by 0 (model/mod.rs:143-146)
+    ref.kv_shift_left(0)
+    assert eng.position() == ref.position == 0
+    got, want = eng.forward(9), ref.forward([9])
+    assert np.abs(got - want).max() <= _tol(want)
+    eng.kv_shift_left(100)                                # more than there is: cleared
+    assert eng.position() == 0
+    eng.close()
