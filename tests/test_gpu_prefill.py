@@ -157,3 +157,51 @@ def test_batched_prefill_rejects_a_prompt_beyond_the_cache(pkg):
         eng.forward_batch([1, cfg.vocab_size + 5])
     assert eng.position() == 3
     eng.close()
+
+
+def test_full_size_llama3_8b_batched_prefill_matches_the_exact_engine(pkg, orc):
+    """BASELINE.json's headline configuration at FULL size, bench protocol: the 127 prompt tokens of `bench.py` through the
+    batched path on one context, the same tokens fed one by one through the decode kernels on another (the same engine
+    instance cannot hold both caches).  The logits of the last prompt token and of 8 greedy steps must agree within the
+    stated tolerance; greedy tokens must be identical wherever the exact engine's top-1/top-2 gap exceeds 4x the error.
+    Then the size-independent properties: a second batched pass over the same prompt is bit-identical (deterministic
+    split-K order), and a 300-token prompt (3 blocks: 128 + 128 + 44) leaves position 300."""
+    cfg = pkg.make_config("llama-3-8b", max_seq_len=384)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    batched = pkg.HipGpuInference.from_model(model, 384)
+    try:
+        assert batched.prefill_is_batched()
+        prompt = [i % 32000 % cfg.vocab_size for i in range(128)]           # main.rs:1787
+        batched.forward_batch(prompt[:-1])
+        lb = [batched.forward(prompt[-1])]
+        toks = []
+        for _ in range(8):
+            toks.append(orc.argmax_last(lb[-1]))
+            lb.append(batched.forward(toks[-1]))
+        batched.reset()
+        batched.forward_batch(prompt[:-1])
+        again = batched.forward(prompt[-1])
+        assert np.array_equal(again, lb[0])
+        batched.reset()
+        batched.forward_batch([(3 * i + 1) % cfg.vocab_size for i in range(300)])
+        assert batched.position() == 300
+    finally:
+        batched.close()
+    exact = pkg.HipGpuInference.from_model(model, 384, flags=pkg.hip_backend.FLAG_EXACT_PREFILL)
+    try:
+        assert not exact.prefill_is_batched()
+        exact.forward_batch(prompt[:-1])
+        le = exact.forward(prompt[-1])
+        errs, gaps = [], []
+        for i in range(9):
+            errs.append(float(np.abs(lb[i] - le).max()))
+            assert errs[-1] <= _tol(le), f"step {i}: max|dlogit| {errs[-1]:.3e} > {_tol(le):.3e}"
+            srt = np.sort(le)
+            gaps.append(float(srt[-1] - srt[-2]))
+            if i < 8:
+                if gaps[-1] > 4 * errs[-1]:
+                    assert orc.argmax_last(le) == toks[i], f"step {i}: greedy token diverged, gap {gaps[-1]:.3e} err {errs[-1]:.3e}"
+                le = exact.forward(toks[i])                                 # both engines are fed the batched engine's tokens
+        print(f"llama-3-8b Q4_K_M, 127-token prompt: max|dlogit|={max(errs):.3e} tol={_tol(le):.3e} min_gap={min(gaps):.3e}")
+    finally:
+        exact.close()
