@@ -195,7 +195,7 @@ hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* 
                          hipStream_t st);
 hipError_t advance_launch(int* state, hipStream_t st);
 hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
-                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st);
+                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st, uint32_t n_tokens = 1);
 
 // attention
 hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,

@@ -37,6 +37,10 @@ struct PfScratch {
   float *hidden = nullptr, *q = nullptr, *part = nullptr, *ssq = nullptr;
   size_t part_bytes = 0;
   int* tokens = nullptr;
+  // MoE layers: routing of the block's tokens, tokens grouped by expert, one expert's gathered input, per-slot expert outputs
+  int *moe_sel = nullptr, *moe_cnt = nullptr, *moe_list = nullptr;
+  float *moe_w = nullptr, *moe_y = nullptr;
+  uint8_t* xh_gather = nullptr;
 };
 
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };

@@ -697,13 +697,21 @@ static bool pf_eligible(const lgh_ctx* c) {
   const lgh_model_desc& d = c->d;
   if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last || d.use_neox_rope) return false;
   const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
-  if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || d.intermediate_size % 256 || KD % 16) return false;
+  if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || KD % 16) return false;
   if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
   for (uint32_t i = c->l0; i < c->l1; i++) {
     const LayerW& L = c->layers[i];
-    if (L.moe()) return false;
-    for (const DevWeight* W : {&L.wq, &L.wk, &L.wv, &L.wo, &L.gate, &L.up, &L.down})
+    for (const DevWeight* W : {&L.wq, &L.wk, &L.wv, &L.wo})
       if (!pf_supported_type(W->type) || W->n % 16) return false;
+    if (L.moe()) {   // experts: tokens are grouped by expert (prefill.hip); up to 8 selected, at most 64 experts
+      if (d.num_experts > (uint32_t)kPfMaxExperts || d.num_experts_per_token == 0 || d.num_experts_per_token > 8) return false;
+      for (const DevWeight* W : {&L.gate_exps, &L.up_exps, &L.down_exps})
+        if (!pf_supported_type(W->type) || W->n % 16 || W->k % 256) return false;
+    } else {
+      if (d.intermediate_size % 256) return false;
+      for (const DevWeight* W : {&L.gate, &L.up, &L.down})
+        if (!pf_supported_type(W->type) || W->n % 16) return false;
+    }
   }
   return true;
 }
@@ -712,21 +720,30 @@ static int pf_ensure(lgh_ctx* c) {
   PfScratch& P = c->pf;
   if (P.ready) return LGH_OK;
   const lgh_model_desc& d = c->d;
-  const uint32_t H = d.hidden_size, QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, F = d.intermediate_size;
-  const uint32_t qkv[3] = {QD, KD, KD}, one[1] = {H}, gu[2] = {F, F};
+  const uint32_t H = d.hidden_size, QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim;
+  bool any_moe = false, any_dense = false;
+  for (uint32_t i = c->l0; i < c->l1; i++) (c->layers[i].moe() ? any_moe : any_dense) = true;
+  const uint32_t F = any_dense ? d.intermediate_size : 0;
+  const uint32_t EI = any_moe ? (d.expert_intermediate_size ? d.expert_intermediate_size : d.intermediate_size) : 0;
+  const uint32_t qkv[3] = {QD, KD, KD}, one[1] = {H};
   size_t pb = pf_part_bytes(qkv, 3, H);
   pb = std::max(pb, pf_part_bytes(one, 1, QD));
-  pb = std::max(pb, pf_part_bytes(gu, 2, H));
-  pb = std::max(pb, pf_part_bytes(one, 1, F));
+  if (F) { const uint32_t gu[2] = {F, F}; pb = std::max({pb, pf_part_bytes(gu, 2, H), pf_part_bytes(one, 1, F)}); }
+  if (EI) { const uint32_t gu[2] = {EI, EI}; pb = std::max({pb, pf_part_bytes(gu, 2, H), pf_part_bytes(one, 1, EI)}); }
+  const uint32_t topk = d.num_experts_per_token ? d.num_experts_per_token : 1;
   int rc;
   struct { void** p; size_t n; } bufs[] = {
       {(void**)&P.xh_h, xh_bytes(H)},           {(void**)&P.xh_attn, xh_bytes(QD)},
-      {(void**)&P.xh_act, xh_bytes(F)},         {(void**)&P.hidden, (size_t)kPfTokens * H * 4},
+      {(void**)&P.xh_act, xh_bytes(std::max(F, EI))}, {(void**)&P.hidden, (size_t)kPfTokens * H * 4},
       {(void**)&P.q, (size_t)kPfTokens * QD * 4},
       {(void**)&P.part, pb},                    {(void**)&P.tokens, (size_t)kPfTokens * 4},
       {(void**)&P.ssq, (size_t)kPfTokens * kPfSsqChunks * 4},
+      {(void**)&P.moe_sel, any_moe ? (size_t)kPfTokens * topk * 4 : 0},  {(void**)&P.moe_w, any_moe ? (size_t)kPfTokens * topk * 4 : 0},
+      {(void**)&P.moe_cnt, any_moe ? (size_t)kPfMaxExperts * 4 : 0},    {(void**)&P.moe_list, any_moe ? (size_t)kPfMaxExperts * kPfTokens * 4 : 0},
+      {(void**)&P.moe_y, any_moe ? (size_t)topk * kPfTokens * H * 4 : 0}, {(void**)&P.xh_gather, any_moe ? xh_bytes(H) : 0},
   };
   for (auto& b : bufs) {
+    if (!b.n) continue;
     if ((rc = dev_alloc(c, b.p, b.n))) return rc;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
@@ -768,13 +785,35 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     const DevWeight* wo[1] = {&L.wo};
     if ((rc = K(pf_gemm_launch(wo, 1, P.xh_attn, P.part, P.part_bytes, m, &S, &nc, st), "wo GEMM"))) return rc;
     if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, L.bo, P.hidden, H, L.ffn_norm, P.xh_h, P.ssq, m, st), "wo epilogue"))) return rc;
-    const DevWeight* gu[2] = {&L.gate, &L.up};
-    if ((rc = K(pf_gemm_launch(gu, 2, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "gate/up GEMM"))) return rc;
-    if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, P.ssq, H, d.norm_eps, m, st), "SwiGLU"))) return rc;
-    const DevWeight* dn[1] = {&L.down};
-    if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, m, &S, &nc, st), "down GEMM"))) return rc;
-    if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, c->layers[li + 1].attn_norm, P.xh_h, P.ssq, m, st), "down epilogue")))
-      return rc;
+    const float* next_nw = c->layers[li + 1].attn_norm;
+    if (!L.moe()) {
+      const DevWeight* gu[2] = {&L.gate, &L.up};
+      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "gate/up GEMM"))) return rc;
+      if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, P.ssq, H, d.norm_eps, m, st), "SwiGLU"))) return rc;
+      const DevWeight* dn[1] = {&L.down};
+      if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, m, &S, &nc, st), "down GEMM"))) return rc;
+      if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, next_nw, P.xh_h, P.ssq, m, st), "down epilogue"))) return rc;
+      continue;
+    }
+    // ---- MoE (moe.rs:321-413): route every token of the block (f32, the decode router), group the (token, slot) pairs by
+    // expert, and run each expert once over its rows: gather -> gate|up GEMM -> SwiGLU -> down GEMM -> rows back to tokens
+    const uint32_t topk = d.num_experts_per_token, EI = L.gate_exps.n;
+    if ((rc = K(moe_router_launch(P.hidden, L.ffn_norm, d.norm_eps, L.router, H, d.num_experts, topk, P.moe_sel, P.moe_w, st, m), "router"))) return rc;
+    if ((rc = K(pf_moe_group_launch(P.moe_sel, m, topk, d.num_experts, P.moe_cnt, P.moe_list, st), "expert grouping"))) return rc;
+    for (uint32_t e = 0; e < d.num_experts; e++) {
+      const int* cnt = P.moe_cnt + e;
+      const int* list = P.moe_list + (size_t)e * kPfTokens;
+      if ((rc = K(pf_moe_gather_launch(P.xh_h, H, list, cnt, P.xh_gather, st), "expert gather"))) return rc;
+      const DevWeight* gu[2] = {&L.gate_exps, &L.up_exps};
+      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_gather, P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert gate/up GEMM"))) return rc;
+      if ((rc = K(pf_swiglu_launch(P.part, S, EI, P.xh_act, P.ssq, H, d.norm_eps, kPfTokens, st, list, cnt), "expert SwiGLU"))) return rc;
+      const DevWeight* dn[1] = {&L.down_exps};
+      if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert down GEMM"))) return rc;
+      if ((rc = K(pf_moe_down_epi_launch(P.part, S, H, list, cnt, P.moe_y, st), "expert rows to tokens"))) return rc;
+    }
+    // h += sum over the selected experts, in selection order, of routing weight * expert output (moe.rs:363-368), then the
+    // next layer's input
+    if ((rc = K(pf_row_epi_launch(P.moe_y, topk, H, 0, nullptr, P.hidden, H, next_nw, P.xh_h, P.ssq, m, st, P.moe_w), "MoE combine"))) return rc;
   }
   c->pos += m;
   c->stats.tokens_processed += m;

@@ -266,6 +266,9 @@ __global__ void __launch_bounds__(512) moe_router_kernel(const float* __restrict
   __shared__ float wsum[16];
   __shared__ float logits[kMaxExperts];
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  x += (size_t)blockIdx.x * hidden;   // one workgroup per token: a single one in decode, a block of prompt tokens in prefill.hip
+  sel += blockIdx.x * top_k;
+  sel_w += blockIdx.x * top_k;
   float inv = 1.0f;
   if (norm_w) {
     float ss = 0.0f;
@@ -311,9 +314,9 @@ __global__ void __launch_bounds__(512) moe_router_kernel(const float* __restrict
 }
 
 hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
-                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st) {
-  if (n_experts > (uint32_t)kMaxExperts || top_k > 8 || top_k > n_experts) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(moe_router_kernel, dim3(1), dim3(512), 0, st, x, norm_w, eps, w, hidden, n_experts, top_k, sel, sel_w);
+                             uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st, uint32_t n_tokens) {
+  if (n_experts > (uint32_t)kMaxExperts || top_k > 8 || top_k > n_experts || n_tokens == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moe_router_kernel, dim3(n_tokens), dim3(512), 0, st, x, norm_w, eps, w, hidden, n_experts, top_k, sel, sel_w);
   return hipGetLastError();
 }
 

@@ -29,19 +29,25 @@ struct PfGemm {
   const uint8_t* xh;     // input activations [128][k] f16, XH layout
   float* part;           // [S][128][ncols]
   uint32_t m_tiles;      // token tiles that hold real tokens
+  const int* m_count;    // optional (MoE): device word with the number of real rows; overrides m_tiles, 0 rows = nothing to do
 };
 
 bool pf_supported_type(int dev_type);
 size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k);
 hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
-                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st);
+                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st, uint32_t expert = 0, const int* m_count = nullptr);
 hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
-                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st);
+                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st, const float* moe_w = nullptr);
 hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
                              const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
                              float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, uint32_t m_tokens, hipStream_t st);
 hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, const float* ssq, uint32_t H, float eps, uint32_t m_tokens,
-                            hipStream_t st);
+                            hipStream_t st, const int* row_tok = nullptr, const int* m_count = nullptr);
+// ---- MoE layers (moe.rs:321-413), tokens grouped by expert: lists[e][i] = token | slot << 8 in token order, counts[e]
+constexpr int kPfMaxExperts = 64;
+hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st);
+hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* list, const int* count, uint8_t* xh_out, hipStream_t st);
+hipError_t pf_moe_down_epi_launch(const float* part, uint32_t S, uint32_t H, const int* list, const int* count, float* y, hipStream_t st);
 hipError_t pf_to_xh_launch(const float* x, uint32_t K, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
 // dequant.hip: rows tokens[0..m) of the embedding table -> dst[m][hidden]
 hipError_t embed_batch_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t m_tokens,

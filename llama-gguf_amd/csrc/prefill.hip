@@ -14,6 +14,9 @@
 //   q, cache --attention (attention.hip, PF variant; causal: token t sees pos0 + t + 1 rows)--> XH(attn)
 //   XH(attn) --GEMM wo--> partials --pf_resid (+bias, +residual)--> h, XH(h * ffn_norm), sums of squares per token
 //   XH --GEMM gate|up--> partials --pf_swiglu (x 1/rms)--> XH(act) --GEMM down--> partials --pf_resid--> h, XH(h * attn_norm')
+// MoE layers (moe.rs:321-413): the f32 decode router runs once per token of the block, the (token, slot) pairs are grouped
+// by expert, and every expert runs ONCE over its rows (gather XH rows -> gate|up GEMM -> SwiGLU -> down GEMM -> rows back
+// to y[slot][token]); pf_resid then adds routing weight * expert output in selection order and the residual.
 // The RMSNorm's 1/rms is a per-token scalar and the GEMM is linear: XH holds h * norm_weight and the kernel that adds
 // up the GEMM's partial sums multiplies by 1/rms (from the sums of squares the producer of h left) — as in the decode path.
 //
@@ -170,6 +173,12 @@ __device__ __forceinline__ h16x8 pf_frag(const PfRaw& r, int pp, int h, h16x2 S,
 
 template <int F>
 __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32_t rg, uint32_t ks, uint8_t* smem) {
+  uint32_t m_tiles = G.m_tiles;
+  if (G.m_count) {   // MoE: this expert's row count lives on the device (no host round trip per layer)
+    const uint32_t cnt = (uint32_t)*G.m_count;
+    if (cnt == 0) return;
+    m_tiles = (cnt + 15) / 16;
+  }
   const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n = lane & 15, c = lane >> 4;
   constexpr uint32_t tb = pf_tile_bytes(F);
@@ -266,7 +275,7 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     const uint32_t col = sg.col0 + (tile0 + r) * 16 + c * 4;
 #pragma unroll
     for (int t = 0; t < kPfMT; t++) {
-      if ((uint32_t)t >= G.m_tiles) continue;
+      if ((uint32_t)t >= m_tiles) continue;
       const f32x4 v = acc[r][t] * (1.0f / kPfScale);
       *reinterpret_cast<f32x4*>(part + (size_t)(t * 16 + n) * G.ncols + col) = v;
     }
@@ -328,7 +337,7 @@ size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k) {
 // Plans and launches one GEMM: up to 3 weight matrices that share the input XH (k elements per token), outputs side by
 // side in the partial-sum buffer.  Returns the split count through *S_out (the consumer adds that many partials).
 hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
-                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st) {
+                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st, uint32_t expert, const int* m_count) {
   if (nw < 1 || nw > 3 || m_tokens == 0 || m_tokens > (uint32_t)kPfTokens) return hipErrorInvalidValue;
   PfGemm G{};
   const uint32_t k = W[0]->k;
@@ -338,8 +347,8 @@ hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, 
   uint32_t rg = 0, col = 0, mask = 0, n_rows[3] = {0, 0, 0};
   for (int i = 0; i < nw; i++) {
     const int f = pf_fmt_of(W[i]->type);
-    if (f < 0 || W[i]->k != k || W[i]->n % 16 || W[i]->n_stack != 1) return hipErrorInvalidValue;
-    G.seg[i].w = W[i]->plane[0];
+    if (f < 0 || W[i]->k != k || W[i]->n % 16 || expert >= W[i]->n_stack) return hipErrorInvalidValue;
+    G.seg[i].w = W[i]->plane[0] + (uint64_t)expert * W[i]->stack_stride[0];   // expert stacks: [expert][tiles]
     G.seg[i].ntiles = W[i]->n / 16;
     G.seg[i].col0 = col;
     G.seg[i].rg_begin = rg;
@@ -355,6 +364,7 @@ hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, 
   G.xh = xh;
   G.part = part;
   G.m_tiles = (m_tokens + 15) / 16;
+  G.m_count = m_count;
   if ((size_t)G.S * kPfTokens * col * 4 > part_bytes) return hipErrorInvalidValue;
   *S_out = G.S;
   *ncols_out = col;
@@ -395,7 +405,8 @@ __device__ __forceinline__ float pf_inv_rms(const float* ssq, uint32_t n_ssq, ui
 // GEMM's partial sums (pf_inv_rms) — no second pass over the row.  S == 0: v = hidden[t][i] as it is (embedding rows).
 __global__ void __launch_bounds__(256) pf_resid_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t col0,
                                                        const float* __restrict__ bias, float* __restrict__ hidden, uint32_t H,
-                                                       const float* __restrict__ nw, uint8_t* __restrict__ xh, float* __restrict__ ssq) {
+                                                       const float* __restrict__ nw, uint8_t* __restrict__ xh, float* __restrict__ ssq,
+                                                       const float* __restrict__ moe_w) {
   __shared__ float s_ss[4];
   const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x, i = ch * 8;
   float ss = 0.0f;
@@ -405,8 +416,14 @@ __global__ void __launch_bounds__(256) pf_resid_kernel(const float* __restrict__
       f32x4 a0 = (f32x4)(0.0f), a1 = (f32x4)(0.0f);
       for (uint32_t s = 0; s < S; s++) {
         const float* row = part + ((size_t)s * kPfTokens + t) * ncols + col0 + i;
-        a0 += *reinterpret_cast<const f32x4*>(row);
-        a1 += *reinterpret_cast<const f32x4*>(row + 4);
+        if (moe_w) {   // MoeLayer::forward (moe.rs:363-368): zero-initialised, += routing weight * expert output in selection order
+          const float w = moe_w[t * S + s];
+          a0 += *reinterpret_cast<const f32x4*>(row) * w;
+          a1 += *reinterpret_cast<const f32x4*>(row + 4) * w;
+        } else {
+          a0 += *reinterpret_cast<const f32x4*>(row);
+          a1 += *reinterpret_cast<const f32x4*>(row + 4);
+        }
       }
       if (bias) { a0 += *reinterpret_cast<const f32x4*>(bias + i); a1 += *reinterpret_cast<const f32x4*>(bias + i + 4); }
       v0 += a0;
@@ -434,9 +451,9 @@ __global__ void __launch_bounds__(256) pf_resid_kernel(const float* __restrict__
 uint32_t pf_ssq_chunks(uint32_t H) { return (H + 2047) / 2048; }
 
 hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t col0, const float* bias, float* hidden, uint32_t H,
-                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st) {
+                             const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st, const float* moe_w) {
   if (H % 8 || (xh && (!nw || !ssq)) || (S && (ncols % 4 || col0 % 4)) || pf_ssq_chunks(H) > (uint32_t)kPfSsqChunks) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_resid_kernel, dim3(pf_ssq_chunks(H), m_tokens), dim3(256), 0, st, part, S, ncols, col0, bias, hidden, H, nw, xh, ssq);
+  hipLaunchKernelGGL(pf_resid_kernel, dim3(pf_ssq_chunks(H), m_tokens), dim3(256), 0, st, part, S, ncols, col0, bias, hidden, H, nw, xh, ssq, moe_w);
   return hipGetLastError();
 }
 
@@ -493,10 +510,12 @@ hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint
 
 // act = silu(gate) * up (simd.rs:598-649) from the partial sums (gate in columns [0, F), up in [F, 2F)) -> XH[t][F]
 __global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict__ part, uint32_t S, uint32_t F, uint8_t* __restrict__ xh,
-                                                        const float* __restrict__ ssq, uint32_t n_ssq, uint32_t H, float eps) {
+                                                        const float* __restrict__ ssq, uint32_t n_ssq, uint32_t H, float eps,
+                                                        const int* __restrict__ row_tok, const int* __restrict__ m_count) {
   const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= F / 8) return;
-  const float inv = pf_inv_rms(ssq, n_ssq, t, H, eps);
+  if (ch >= F / 8 || (m_count && t >= (uint32_t)*m_count)) return;
+  // MoE: row t of this expert's batch is token row_tok[t] & 0xFF (its 1/rms), dense: row t is token t
+  const float inv = pf_inv_rms(ssq, n_ssq, row_tok ? (uint32_t)row_tok[t] & 0xFFu : t, H, eps);
   float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t s = 0; s < S; s++) {
     const float* row = part + ((size_t)s * kPfTokens + t) * (2 * (size_t)F);
@@ -512,9 +531,63 @@ __global__ void __launch_bounds__(256) pf_swiglu_kernel(const float* __restrict_
 }
 
 hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, const float* ssq, uint32_t H, float eps, uint32_t m_tokens,
-                            hipStream_t st) {
+                            hipStream_t st, const int* row_tok, const int* m_count) {
   if (F % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_swiglu_kernel, dim3((F / 8 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, F, xh, ssq, pf_ssq_chunks(H), H, eps);
+  hipLaunchKernelGGL(pf_swiglu_kernel, dim3((F / 8 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, F, xh, ssq, pf_ssq_chunks(H), H, eps, row_tok, m_count);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MoE layers: tokens grouped by expert so that every expert's matrices are read once per block of tokens
+// ------------------------------------------------------------------------------------------------
+// lists[e][i] = token | slot << 8 for the i-th (token, slot) routed to expert e, in token order; counts[e]
+__global__ void __launch_bounds__(64) pf_moe_group_kernel(const int* __restrict__ sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts,
+                                                          int* __restrict__ counts, int* __restrict__ lists) {
+  const uint32_t e = threadIdx.x;
+  if (e >= n_experts) return;
+  int n = 0;
+  for (uint32_t t = 0; t < m_tokens; t++)
+    for (uint32_t s = 0; s < top_k; s++)
+      if ((uint32_t)sel[t * top_k + s] == e && n < kPfTokens) lists[e * kPfTokens + n++] = (int)(t | s << 8);
+  counts[e] = n;
+}
+
+hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st) {
+  if (n_experts > (uint32_t)kPfMaxExperts || top_k == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_group_kernel, dim3(1), dim3(64), 0, st, sel, m_tokens, top_k, n_experts, counts, lists);
+  return hipGetLastError();
+}
+
+// row i of the expert's XH batch = the XH row of token list[i] (the chunk swizzle depends on the row index: re-swizzled)
+__global__ void __launch_bounds__(256) pf_moe_gather_kernel(const uint8_t* __restrict__ xh, const int* __restrict__ list, const int* __restrict__ count,
+                                                            uint8_t* __restrict__ xh_out) {
+  const uint32_t slab = blockIdx.x, i = blockIdx.y * 8 + (threadIdx.x >> 5), q = threadIdx.x & 31;
+  if (i >= (uint32_t)*count) return;
+  const uint32_t ts = (uint32_t)list[i] & 0xFFu;
+  const u32x4 v = *reinterpret_cast<const u32x4*>(xh + (size_t)slab * kPfSlabBytes + ts * 512 + ((q ^ (ts & 15)) << 4));
+  *reinterpret_cast<u32x4*>(xh_out + (size_t)slab * kPfSlabBytes + i * 512 + ((q ^ (i & 15)) << 4)) = v;
+}
+
+hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* list, const int* count, uint8_t* xh_out, hipStream_t st) {
+  if (K % 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_gather_kernel, dim3(K / 256, kPfTokens / 8), dim3(256), 0, st, xh, list, count, xh_out);
+  return hipGetLastError();
+}
+
+// the expert's down-projection rows back to their tokens: y[slot][token][:] = sum of the partial sums of row i
+__global__ void __launch_bounds__(256) pf_moe_down_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t H, const int* __restrict__ list,
+                                                              const int* __restrict__ count, float* __restrict__ y) {
+  const uint32_t i = blockIdx.y, c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= (uint32_t)*count || c4 >= H) return;
+  const uint32_t tok = (uint32_t)list[i] & 0xFFu, slot = (uint32_t)list[i] >> 8;
+  f32x4 a = (f32x4)(0.0f);
+  for (uint32_t s = 0; s < S; s++) a += *reinterpret_cast<const f32x4*>(part + ((size_t)s * kPfTokens + i) * H + c4);
+  *reinterpret_cast<f32x4*>(y + ((size_t)slot * kPfTokens + tok) * H + c4) = a;
+}
+
+hipError_t pf_moe_down_epi_launch(const float* part, uint32_t S, uint32_t H, const int* list, const int* count, float* y, hipStream_t st) {
+  if (H % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_down_epi_kernel, dim3((H / 4 + 255) / 256, kPfTokens), dim3(256), 0, st, part, S, H, list, count, y);
   return hipGetLastError();
 }
 

@@ -80,9 +80,12 @@ def _tol(want):
 
 @pytest.mark.parametrize("name,mix,n_prompt", [("test-dense", "Q4_K_M", 41), ("test-dense", "Q8_0", 128), ("test-dense", "Q4_0", 17),
                                                ("test-dense", "Q5_K_M", 64), ("test-dense", "Q6_K", 33),
-                                               ("test-dense-d128", "Q4_K_M", 150), ("test-dense-d128", "Q5_K_M", 129)])
+                                               ("test-dense-d128", "Q4_K_M", 150), ("test-dense-d128", "Q5_K_M", 129),
+                                               ("test-moe", "Q5_K_M", 70), ("test-moe", "Q4_K_M", 140)])
 def test_batched_prefill_matches_token_by_token_and_oracle(pkg, orc, name, mix, n_prompt):
-    """The KV cache left by the batched path, seen through the logits of the following tokens."""
+    """The KV cache left by the batched path, seen through the logits of the following tokens.  The MoE cases group the
+    block's tokens by expert; a token whose two best router logits are nearly tied may pick a different expert than the
+    exact path does (the router sees f16-rounded history) — the logits tolerance covers what that does on these models."""
     cfg, ref, exact, batched = _pair(pkg, orc, name, mix, max_seq=256)
     assert batched.prefill_is_batched() and not exact.prefill_is_batched()
     prompt = [(7 * i + 3) % cfg.vocab_size for i in range(n_prompt)]
@@ -131,9 +134,10 @@ def test_batched_prefill_continues_an_existing_sequence(pkg, orc):
 
 
 def test_models_outside_the_batched_path_prefill_exactly(pkg, orc):
-    """MoE layers (and any format mix without tile layouts) keep the token-by-token path: bit-identical to prefill_token."""
-    cfg = pkg.make_config("test-moe", max_seq_len=64)
-    model = pkg.SynthModel(cfg, mix="Q5_K_M")
+    """Format mixes without tile layouts (here Q5_0: dequantized to f32 at upload) keep the token-by-token path:
+    bit-identical to prefill_token."""
+    cfg = pkg.make_config("test-dense", max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix="Q5_0")
     a, b = pkg.HipGpuInference.from_model(model, 64), pkg.HipGpuInference.from_model(model, 64)
     assert not a.prefill_is_batched()
     prompt = [3, 500, 41, 7, 900, 12]
