@@ -180,7 +180,7 @@ int lgh_prefill_token(lgh_ctx* ctx, uint32_t token_id);
  * (dense or MoE) whose 2-D weights are all in matrix-core tile layouts (Q4_K, Q5_K, Q6_K, Q8_0, Q4_0 with k % 256 == 0)
  * take the batched path: blocks of up to 128 tokens, one f16-MFMA GEMM per weight (MoE: per expert, over
  * the tokens routed to it), causal attention over the block; the KV cache it leaves equals the token-by-token one within
- * 1e-2 relative (f16 operands, f32 accumulation).  Everything else (NeoX RoPE, pipeline stages, other formats), and any
+ * 1e-2 relative (f16 operands, f32 accumulation).  Everything else (pipeline stages, other formats), and any
  * context created with LGH_FLAG_EXACT_PREFILL, runs n exact prefill_tokens. */
 int lgh_prefill_batch(lgh_ctx* ctx, const uint32_t* tokens, size_t n);
 /* 1 when lgh_prefill_batch will take the batched GEMM path for this (finalized) context, else 0 */

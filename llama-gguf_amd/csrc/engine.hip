@@ -695,7 +695,7 @@ static int set_token(lgh_ctx* c, uint32_t token) {
 // ------------------------------------------------------------------------------------------------
 static bool pf_eligible(const lgh_ctx* c) {
   const lgh_model_desc& d = c->d;
-  if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last || d.use_neox_rope) return false;
+  if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last) return false;
   const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
   if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || KD % 16) return false;
   if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
@@ -775,7 +775,7 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     const DevWeight* qkv[3] = {&L.wq, &L.wk, &L.wv};
     if ((rc = K(pf_gemm_launch(qkv, 3, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "qkv GEMM"))) return rc;
     if ((rc = K(pf_qkv_epi_launch(P.part, S, nc, QD, KD, d.head_dim, L.bq, L.bk, L.bv, c->rope_cs, pos0, d.max_seq_len, P.q, L.kcache, L.vcache, P.ssq, H,
-                                  d.norm_eps, m, st),
+                                  d.norm_eps, (int)d.use_neox_rope, m, st),
                 "qkv epilogue")))
       return rc;
     if (li + 1 == c->l1) break;   // the last layer's K/V rows are written; its output would be discarded (prefill has no logits)

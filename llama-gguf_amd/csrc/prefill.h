@@ -40,7 +40,7 @@ hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint
                              const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st, const float* moe_w = nullptr);
 hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
                              const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
-                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, uint32_t m_tokens, hipStream_t st);
+                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, int neox, uint32_t m_tokens, hipStream_t st);
 hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh, const float* ssq, uint32_t H, float eps, uint32_t m_tokens,
                             hipStream_t st, const int* row_tok = nullptr, const int* m_count = nullptr);
 // ---- MoE layers (moe.rs:321-413), tokens grouped by expert: lists[e][i] = token | slot << 8 in token order, counts[e]

@@ -457,54 +457,58 @@ hipError_t pf_row_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint
   return hipGetLastError();
 }
 
-// q, k, v of token t: partial sums (+bias), RoPE on the (2i, 2i+1) pairs of q and k at position pos0 + t
-// (ops.rs:1285-1337), q -> qbuf[t][QD], k / v -> cache rows pos0 + t (layers.rs:577-600)
+// q, k, v of token t: partial sums (+bias), RoPE on the (2i, 2i+1) — NeoX: (i, i + d/2) — pairs of q and k at position
+// pos0 + t (ops.rs:1285-1337), q -> qbuf[t][QD], k / v -> cache rows pos0 + t (layers.rs:577-600)
 __global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD,
                                                          uint32_t head_dim, const float* __restrict__ bq, const float* __restrict__ bk,
                                                          const float* __restrict__ bv, const float* __restrict__ rope_cs, uint32_t pos0,
                                                          uint32_t max_seq, float* __restrict__ qbuf, float* __restrict__ kcache,
                                                          float* __restrict__ vcache, const float* __restrict__ ssq, uint32_t n_ssq,
-                                                         uint32_t H, float eps) {
+                                                         uint32_t H, float eps, int neox) {
   const uint32_t t = blockIdx.y, pos = pos0 + t, half = head_dim / 2;
   const float inv = pf_inv_rms(ssq, n_ssq, t, H, eps);
-  const uint32_t npairs = (QD + 2 * KD) / 2;
+  const uint32_t npairs = (QD + 2 * KD) / 2, nq = QD / 2, nk = KD / 2;
   for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p < npairs; p += gridDim.x * 256) {
-    const uint32_t col = 2 * p;
+    // the two columns of pair p: (2i, 2i+1) of a head for RopeType::Normal, (i, i + d/2) for NeoX (ops.rs:1316-1331); V: plain pairs
+    const bool isq = p < nq, isk = !isq && p < nq + nk;
+    const uint32_t pr = isq ? p : isk ? p - nq : p - nq - nk;           // pair index inside its region
+    const uint32_t base = isq ? 0 : isk ? QD : QD + KD;                 // first column of the region
+    const bool rot = isq || isk;
+    const uint32_t i = rot ? (neox ? pr % half : (2 * pr % head_dim) / 2) : 0;
+    const uint32_t r0 = rot && neox ? (pr / half) * head_dim + i : 2 * pr, r1 = rot && neox ? r0 + half : r0 + 1;   // rows of the matrix
     float x0 = 0.0f, x1 = 0.0f;
     for (uint32_t s = 0; s < S; s++) {
-      const float2 v = *reinterpret_cast<const float2*>(part + ((size_t)s * kPfTokens + t) * ncols + col);
-      x0 += v.x;
-      x1 += v.y;
+      const float* row = part + ((size_t)s * kPfTokens + t) * ncols + base;
+      x0 += row[r0];
+      x1 += row[r1];
     }
     x0 *= inv;
     x1 *= inv;
-    if (col < QD + KD) {
-      const bool isq = col < QD;
-      const uint32_t row = isq ? col : col - QD;
-      const float* b = isq ? bq : bk;
-      if (b) { x0 += b[row]; x1 += b[row + 1]; }
-      const uint32_t i = (row % head_dim) / 2;
+    const float* b = isq ? bq : isk ? bk : bv;
+    if (b) { x0 += b[r0]; x1 += b[r1]; }
+    float y0 = x0, y1 = x1;
+    if (rot) {
       const float cs = rope_cs[((size_t)pos * half + i) * 2], sn = rope_cs[((size_t)pos * half + i) * 2 + 1];
-      const float y0 = x0 * cs - x1 * sn, y1 = x0 * sn + x1 * cs;
-      float* dst = isq ? qbuf + (size_t)t * QD + row : kcache + ((size_t)(row / head_dim) * max_seq + pos) * head_dim + (row % head_dim);
-      dst[0] = y0;
-      dst[1] = y1;
+      y0 = x0 * cs - x1 * sn;
+      y1 = x0 * sn + x1 * cs;
+    }
+    if (isq) {
+      qbuf[(size_t)t * QD + r0] = y0;
+      qbuf[(size_t)t * QD + r1] = y1;
     } else {
-      const uint32_t row = col - QD - KD;
-      if (bv) { x0 += bv[row]; x1 += bv[row + 1]; }
-      float* dst = vcache + ((size_t)(row / head_dim) * max_seq + pos) * head_dim + (row % head_dim);
-      dst[0] = x0;
-      dst[1] = x1;
+      float* cache = isk ? kcache : vcache;
+      cache[((size_t)(r0 / head_dim) * max_seq + pos) * head_dim + (r0 % head_dim)] = y0;
+      cache[((size_t)(r1 / head_dim) * max_seq + pos) * head_dim + (r1 % head_dim)] = y1;
     }
   }
 }
 
 hipError_t pf_qkv_epi_launch(const float* part, uint32_t S, uint32_t ncols, uint32_t QD, uint32_t KD, uint32_t head_dim, const float* bq,
                              const float* bk, const float* bv, const float* rope_cs, uint32_t pos0, uint32_t max_seq, float* qbuf,
-                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, uint32_t m_tokens, hipStream_t st) {
+                             float* kcache, float* vcache, const float* ssq, uint32_t H, float eps, int neox, uint32_t m_tokens, hipStream_t st) {
   if (head_dim % 2 || ncols != QD + 2 * KD) return hipErrorInvalidValue;
   hipLaunchKernelGGL(pf_qkv_epi_kernel, dim3(((QD + 2 * KD) / 2 + 255) / 256, m_tokens), dim3(256), 0, st, part, S, ncols, QD, KD, head_dim, bq, bk, bv, rope_cs, pos0, max_seq,
-                     qbuf, kcache, vcache, ssq, pf_ssq_chunks(H), H, eps);
+                     qbuf, kcache, vcache, ssq, pf_ssq_chunks(H), H, eps, neox);
   return hipGetLastError();
 }
 

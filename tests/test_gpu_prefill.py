@@ -209,3 +209,26 @@ def test_full_size_llama3_8b_batched_prefill_matches_the_exact_engine(pkg, orc):
         print(f"llama-3-8b Q4_K_M, 127-token prompt: max|dlogit|={max(errs):.3e} tol={_tol(le):.3e} min_gap={min(gaps):.3e}")
     finally:
         exact.close()
+
+
+@pytest.mark.parametrize("neox", [0, 1])
+def test_batched_prefill_with_biases_and_neox_rope(pkg, orc, neox):
+    """Qwen2-style layers: q/k/v biases (layers.rs:438-470) and NeoX pairing (i, i + d/2) of the rotation (ops.rs:1316-1331),
+    against the CPU oracle and the exact engine."""
+    cfg = pkg.make_config("test-dense-d128", max_seq_len=96, use_neox_rope=neox)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M", with_bias=True)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    exact = pkg.HipGpuInference.from_model(model, 96, flags=pkg.hip_backend.FLAG_EXACT_PREFILL)
+    batched = pkg.HipGpuInference.from_model(model, 96)
+    assert batched.prefill_is_batched()
+    prompt = [(9 * i + 4) % cfg.vocab_size for i in range(50)]
+    exact.forward_batch(prompt[:-1])
+    batched.forward_batch(prompt[:-1])
+    le, lb, lo = exact.forward(prompt[-1]), batched.forward(prompt[-1]), ref.forward(prompt)
+    assert np.abs(le - lo).max() <= 2e-3 * np.abs(lo).max() + 2e-3          # the exact path: the decode tolerance
+    assert np.abs(lb - lo).max() <= _tol(lo) and np.abs(lb - le).max() <= _tol(le)
+    exact.close()
+    batched.close()
