@@ -72,6 +72,11 @@ class HipGpuInference {
     return logits;
   }
   void prefill_token(uint32_t token_id) { check(lgh_prefill_token(h_, token_id)); }
+  // GpuOnlyInference::forward_batch minus the final forward (gpu_only.rs:776-790); batched f16-GEMM path when the model allows
+  void forward_batch(const std::vector<uint32_t>& tokens) { check(lgh_prefill_batch(h_, tokens.data(), tokens.size())); }
+  bool prefill_is_batched() { return lgh_prefill_is_batched(h_) != 0; }
+  void kv_truncate(size_t new_len) { check(lgh_kv_truncate(h_, new_len)); }        // KVCache::truncate (model/mod.rs:130-134)
+  void kv_shift_left(size_t amount) { check(lgh_kv_shift_left(h_, amount)); }      // KVCache::shift_left (model/mod.rs:142-172)
   void reset() { lgh_reset(h_); }                      // infallible, O(1)
   size_t position() const { return lgh_position(h_); }
   uint32_t forward_argmax(uint32_t token_id) {
