@@ -276,8 +276,8 @@ def run_pipeline(args, pkg):
     stage = pkg.pipeline.HipStage(eng, torch, dev)
     dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
-    for t in prompt:                                   # token-by-token prefill through the pipeline
-        dec.step(t)
+    dec.prefill(prompt[:-1])                           # blocks of hidden vectors per hop where the stages have the batched path
+    dec.step(prompt[-1])
     tok = prompt[-1]
     for _ in range(W):
         tok = dec.step(tok)

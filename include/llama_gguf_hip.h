@@ -225,6 +225,12 @@ int lgh_stage_hidden_buffer(lgh_ctx* ctx, void** device_ptr);     /* in/out resi
  * projection (+ device arg-max into *next_token if non-NULL).  Asynchronous on the stream unless
  * logits_out / next_token are requested. */
 int lgh_stage_forward(lgh_ctx* ctx, uint32_t token_id, int want_logits, float* logits_out, uint32_t* next_token);
+/* A block of up to 128 prompt tokens through this stage's layers on the batched path (lgh_prefill_batch's, for layer
+ * ranges).  The first stage reads `tokens`; any other stage reads the block of hidden vectors [n][hidden_size] f32 at
+ * lgh_stage_hidden_block_buffer, where a stage that is not the last leaves its output block for the next hop.
+ * LGH_UNSUPPORTED when the context has no batched path (feed the tokens through lgh_stage_forward then). */
+int lgh_stage_prefill_batch(lgh_ctx* ctx, const uint32_t* tokens, size_t n);
+int lgh_stage_hidden_block_buffer(lgh_ctx* ctx, void** device_ptr);
 
 /* ---- per-op surface: the `Backend` trait ops on the path (src/backend/mod.rs:29-265), host tensors
  * in / host tensors out, for parity tests of each kernel against the CPU backend. ---- */

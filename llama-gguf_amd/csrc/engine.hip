@@ -628,6 +628,33 @@ static int enqueue_token(lgh_ctx* c, int mode) {
   return LGH_OK;
 }
 
+static int check_chain(lgh_ctx* c);
+
+// One token through the context's kernels, launched eagerly, before any of them is first launched inside a stream
+// capture.  Measured on ROCm 7.0 / MI355X: a kernel whose FIRST launch in the process happens during a capture is not
+// replayed with the graph — a pipeline stage behind the first (advance + stand-alone XQ kernels, which only such stages
+// use) then decoded from a stale position in a fresh process and correctly in every later context of the same process
+// (tools/diag_stage_first_capture.py).  Token 0 at position 0 with whatever is in the buffers: it writes K/V
+// row 0 of every layer, which the sequence's real first token overwrites before anything reads it.
+static int warm_kernels(lgh_ctx* c) {
+  if (c->d.flags & LGH_FLAG_NO_GRAPH) return LGH_OK;
+  int rc = LGH_OK;
+  const bool keep_direct = c->attn_direct;
+  for (int v = 0; v < 2 && !rc; v++) {
+    if (v == 1 && c->direct_attn_max_kv == 0) break;
+    c->attn_direct = v == 1;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
+    for (int mode : {c->last ? MODE_GREEDY : MODE_PREFILL, MODE_PREFILL})   // the last stage: with and without the output head
+      if (!rc) rc = enqueue_token(c, mode);
+  }
+  c->attn_direct = keep_direct;
+  for (auto& q : c->xqs) q.fresh = false;
+  if (rc) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return check_chain(c);
+}
+
 static int ensure_graph(lgh_ctx* c, int mode) {
   const int var = c->attn_direct ? 1 : 0;
   if (c->graph[mode][var]) return LGH_OK;
@@ -695,7 +722,7 @@ static int set_token(lgh_ctx* c, uint32_t token) {
 // ------------------------------------------------------------------------------------------------
 static bool pf_eligible(const lgh_ctx* c) {
   const lgh_model_desc& d = c->d;
-  if ((d.flags & LGH_FLAG_EXACT_PREFILL) || !c->first || !c->last) return false;
+  if (d.flags & LGH_FLAG_EXACT_PREFILL) return false;
   const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
   if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || KD % 16) return false;
   if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
@@ -748,12 +775,17 @@ static int pf_ensure(lgh_ctx* c) {
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
   }
+  // the zero-fills are done before anybody else (another stream, a peer's copy into the stage block) touches the buffers
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   P.part_bytes = pb;
   P.ready = true;
   return LGH_OK;
 }
 
-// m <= 128 prompt tokens at positions pos .. pos+m-1: fills every layer's K/V rows (nothing else of a prefill survives)
+// m <= 128 prompt tokens at positions pos .. pos+m-1: fills every owned layer's K/V rows.  The first stage starts from the
+// tokens' embedding rows, any other stage from the block of hidden vectors its predecessor left in pf.hidden; a stage that
+// is not the last leaves its output block there (the last one stops after its final layer's K/V rows: nothing else of a
+// prefill survives).
 static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
   int rc = pf_ensure(c);
   if (rc) return rc;
@@ -765,8 +797,10 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
   auto K = [&](hipError_t e, const char* what) -> int {
     return e == hipSuccess ? LGH_OK : fail(c, LGH_OPERATION_FAILED, std::string("batched prefill, ") + what + ": " + hipGetErrorString(e));
   };
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, tokens, (size_t)m * 4, hipMemcpyHostToDevice, st));
-  if ((rc = K(embed_batch_launch(c->embd_type, c->embd_raw, P.tokens, P.hidden, H, m, st), "embedding"))) return rc;
+  if (c->first) {
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, tokens, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    if ((rc = K(embed_batch_launch(c->embd_type, c->embd_raw, P.tokens, P.hidden, H, m, st), "embedding"))) return rc;
+  }
   if ((rc = K(pf_row_epi_launch(nullptr, 0, 0, 0, nullptr, P.hidden, H, c->layers[c->l0].attn_norm, P.xh_h, P.ssq, m, st), "attn_norm"))) return rc;
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   for (uint32_t li = c->l0; li < c->l1; li++) {
@@ -778,21 +812,22 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
                                   d.norm_eps, (int)d.use_neox_rope, m, st),
                 "qkv epilogue")))
       return rc;
-    if (li + 1 == c->l1) break;   // the last layer's K/V rows are written; its output would be discarded (prefill has no logits)
+    if (li + 1 == c->l1 && c->last) break;   // the model's last layer: its K/V rows are written, its output would be discarded
     if ((rc = K(attn_prefill_launch(P.q, L.kcache, L.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, pos0, m, P.xh_attn, st),
                 "attention")))
       return rc;
     const DevWeight* wo[1] = {&L.wo};
     if ((rc = K(pf_gemm_launch(wo, 1, P.xh_attn, P.part, P.part_bytes, m, &S, &nc, st), "wo GEMM"))) return rc;
     if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, L.bo, P.hidden, H, L.ffn_norm, P.xh_h, P.ssq, m, st), "wo epilogue"))) return rc;
-    const float* next_nw = c->layers[li + 1].attn_norm;
+    const float* next_nw = li + 1 < c->l1 ? c->layers[li + 1].attn_norm : nullptr;   // nullptr: the block goes to the next stage as f32
+    uint8_t* next_xh = next_nw ? P.xh_h : nullptr;
     if (!L.moe()) {
       const DevWeight* gu[2] = {&L.gate, &L.up};
       if ((rc = K(pf_gemm_launch(gu, 2, P.xh_h, P.part, P.part_bytes, m, &S, &nc, st), "gate/up GEMM"))) return rc;
       if ((rc = K(pf_swiglu_launch(P.part, S, F, P.xh_act, P.ssq, H, d.norm_eps, m, st), "SwiGLU"))) return rc;
       const DevWeight* dn[1] = {&L.down};
       if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, m, &S, &nc, st), "down GEMM"))) return rc;
-      if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, next_nw, P.xh_h, P.ssq, m, st), "down epilogue"))) return rc;
+      if ((rc = K(pf_row_epi_launch(P.part, S, nc, 0, nullptr, P.hidden, H, next_nw, next_xh, P.ssq, m, st), "down epilogue"))) return rc;
       continue;
     }
     // ---- MoE (moe.rs:321-413): route every token of the block (f32, the decode router), group the (token, slot) pairs by
@@ -813,7 +848,7 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     }
     // h += sum over the selected experts, in selection order, of routing weight * expert output (moe.rs:363-368), then the
     // next layer's input
-    if ((rc = K(pf_row_epi_launch(P.moe_y, topk, H, 0, nullptr, P.hidden, H, next_nw, P.xh_h, P.ssq, m, st, P.moe_w), "MoE combine"))) return rc;
+    if ((rc = K(pf_row_epi_launch(P.moe_y, topk, H, 0, nullptr, P.hidden, H, next_nw, next_xh, P.ssq, m, st, P.moe_w), "MoE combine"))) return rc;
   }
   c->pos += m;
   c->stats.tokens_processed += m;
@@ -1068,7 +1103,7 @@ int lgh_finalize(lgh_ctx* c) {
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   c->finalized = true;
   c->pos = 0;
-  return LGH_OK;
+  return warm_kernels(c);
 }
 
 void lgh_destroy(lgh_ctx* c) {
@@ -1113,11 +1148,34 @@ int lgh_prefill_token(lgh_ctx* c, uint32_t token) {
 
 int lgh_prefill_is_batched(lgh_ctx* c) { return c && c->finalized && pf_eligible(c) ? 1 : 0; }
 
+int lgh_stage_hidden_block_buffer(lgh_ctx* c, void** p) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!p) return fail(c, LGH_INVALID_ARGUMENT, "p is NULL");
+  if (!pf_eligible(c)) return fail(c, LGH_UNSUPPORTED, "this context has no batched prompt path");
+  if ((rc = pf_ensure(c))) return rc;
+  *p = c->pf.hidden;
+  return LGH_OK;
+}
+
+int lgh_stage_prefill_batch(lgh_ctx* c, const uint32_t* tokens, size_t n) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!pf_eligible(c)) return fail(c, LGH_UNSUPPORTED, "this context has no batched prompt path");
+  if (n == 0 || n > (size_t)kPfTokens) return fail(c, LGH_INVALID_ARGUMENT, "a stage block holds 1..128 tokens");
+  if (c->first && !tokens) return fail(c, LGH_INVALID_ARGUMENT, "the first stage needs the token ids");
+  if (c->pos + n > c->d.max_seq_len) return fail(c, LGH_INVALID_ARGUMENT, "prompt block exceeds max_seq_len");
+  if (c->first)
+    for (size_t i = 0; i < n; i++)
+      if (tokens[i] >= c->d.vocab_size) return fail(c, LGH_INVALID_ARGUMENT, "token id exceeds vocab size");
+  return prefill_block(c, tokens, (uint32_t)n);
+}
+
 int lgh_prefill_batch(lgh_ctx* c, const uint32_t* tokens, size_t n) {
   int rc = check_ready(c);
   if (rc) return rc;
   if (n && !tokens) return fail(c, LGH_INVALID_ARGUMENT, "tokens is NULL");
-  if (n >= 2 && pf_eligible(c)) {
+  if (n >= 2 && c->first && c->last && pf_eligible(c)) {
     if (c->pos + n > c->d.max_seq_len)
       return fail(c, LGH_INVALID_ARGUMENT, "prompt of " + std::to_string(n) + " tokens at position " + std::to_string(c->pos) + " exceeds max_seq_len");
     for (size_t i = 0; i < n; i++)

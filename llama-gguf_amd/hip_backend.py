@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat",
     "lgh_op_add", "lgh_op_mul", "lgh_op_scale", "lgh_op_silu", "lgh_op_gelu", "lgh_op_softmax", "lgh_op_matmul", "lgh_op_matvec",
     "lgh_op_matvec_q", "lgh_op_attention", "lgh_backend_create", "lgh_backend_destroy", "lgh_backend_load_weight",
-    "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_kv_truncate", "lgh_kv_shift_left", "lgh_forward_argmax", "lgh_decode_greedy",
+    "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_kv_truncate", "lgh_kv_shift_left", "lgh_stage_prefill_batch", "lgh_stage_hidden_block_buffer", "lgh_forward_argmax", "lgh_decode_greedy",
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
@@ -104,6 +104,7 @@ def load_library() -> C.CDLL:
         "lgh_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_prefill_is_batched": (C.c_int, [vp]),
         "lgh_op_mat_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, sz, sz, sz]), "lgh_reset": (None, [vp]), "lgh_position": (sz, [vp]),
         "lgh_kv_truncate": (C.c_int, [vp, sz]), "lgh_kv_shift_left": (C.c_int, [vp, sz]),
+        "lgh_stage_prefill_batch": (C.c_int, [vp, vp, sz]), "lgh_stage_hidden_block_buffer": (C.c_int, [vp, C.POINTER(vp)]),
         "lgh_forward_argmax": (C.c_int, [vp, u32, C.POINTER(u32)]),
         "lgh_decode_greedy": (C.c_int, [vp, u32, sz, vp]),
         "lgh_last_error": (C.c_char_p, [vp]), "lgh_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
@@ -266,6 +267,17 @@ class HipGpuInference:
         p = C.c_void_p()
         self._call(load_library().lgh_stage_hidden_buffer(self._h, C.byref(p)))
         return p.value
+
+    def stage_hidden_block_ptr(self) -> int:
+        """Device address of the [128][hidden] f32 block the batched prompt path hands from stage to stage."""
+        p = C.c_void_p()
+        self._call(load_library().lgh_stage_hidden_block_buffer(self._h, C.byref(p)))
+        return p.value
+
+    def stage_prefill_batch(self, tokens: Optional[Sequence[int]], n: int) -> None:
+        """Up to 128 prompt tokens through this stage's layers on the batched path (`tokens` is read on the first stage)."""
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32) if tokens is not None else None
+        self._call(load_library().lgh_stage_prefill_batch(self._h, toks.ctypes.data if toks is not None else None, n))
 
     def stage_forward(self, token_id: int = 0, want_logits: bool = False, argmax: bool = False):
         logits = np.empty(self.vocab_size, dtype=np.float32) if (want_logits and not argmax) else None

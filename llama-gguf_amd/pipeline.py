@@ -74,6 +74,30 @@ class PipelineDecoder:
             return int(st.token_buf[0].item())
         return -1
 
+    def prefill(self, tokens) -> None:
+        """The prompt (all ranks pass the same token list; only rank 0 reads the ids).  Stages with a batched prompt path
+        (`stage.block` / `stage.run_block`) move blocks of up to `stage.block_tokens` hidden vectors per hop, otherwise the
+        tokens go through one by one as in `step` (nothing is returned either way: a prefill only fills the caches)."""
+        st = self.stage
+        bt = getattr(st, "block_tokens", 0)
+        if not bt:
+            for t in tokens:
+                if not self.first:
+                    self.comm.recv(st.hidden, self.rank - 1)
+                st.run(int(t) if self.first else 0, False)
+                if not self.last:
+                    self.comm.send(st.hidden, self.rank + 1)
+            return
+        hs = st.hidden.numel()
+        for i in range(0, len(tokens), bt):
+            chunk = [int(t) for t in tokens[i:i + bt]]
+            view = st.block[:len(chunk) * hs]
+            if not self.first:
+                self.comm.recv(view, self.rank - 1)
+            st.run_block(chunk if self.first else None, len(chunk))
+            if not self.last:
+                self.comm.send(view, self.rank + 1)
+
     def decode(self, first_token: int, n_steps: int) -> List[int]:
         out, tok = [], first_token
         for _ in range(n_steps):
@@ -98,6 +122,14 @@ class HipStage:
         self.token_buf = torch.zeros(1, dtype=torch.int32, device=device)
         # kernels and the RCCL hop are ordered on torch's current stream
         engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        # batched prompt path (lgh_stage_prefill_batch): a [128][hidden] f32 block per hop instead of one vector per token
+        self.block_tokens = 0
+        if engine.prefill_is_batched():
+            self.block_tokens = 128
+            self.block = torch.as_tensor(DevicePtrTensor(engine.stage_hidden_block_ptr(), 128 * engine.hidden_size), device=device)
+
+    def run_block(self, tokens, n: int) -> None:
+        self.engine.stage_prefill_batch(tokens, n)
 
     def run(self, token: int, last: bool) -> int:
         if last:

@@ -163,6 +163,7 @@ def test_pipeline_stages_reproduce_single_stage(pkg, orc):
         s0.stage_forward(tok)
         s0.synchronize()
         assert hip.hipMemcpy(s1.stage_hidden_ptr(), s0.stage_hidden_ptr(), cfg.hidden_size * 4, 3) == 0  # D2D
+        assert hip.hipDeviceSynchronize() == 0   # a device-to-device hipMemcpy may return before it is done
         got = s1.stage_forward(0, want_logits=True)
         assert np.array_equal(got, want)
     for e in (full, s0, s1):

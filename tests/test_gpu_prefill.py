@@ -232,3 +232,44 @@ def test_batched_prefill_with_biases_and_neox_rope(pkg, orc, neox):
     assert np.abs(lb - lo).max() <= _tol(lo) and np.abs(lb - le).max() <= _tol(le)
     exact.close()
     batched.close()
+
+
+@pytest.mark.parametrize("name,mix,split", [("test-dense-d128", "Q4_K_M", 2), ("test-dense-d128", "Q4_K_M", 1), ("test-moe", "Q5_K_M", 1)])
+def test_stage_blocks_reproduce_the_single_context_prompt_pass(pkg, name, mix, split):
+    """lgh_stage_prefill_batch: two stage contexts on one GPU, the [n][hidden] f32 block handed over device to device,
+    leave the same K/V rows as one full context (bitwise: the same kernels see the same f32 block), seen through the
+    logits of the decode steps that follow; 150 tokens = two blocks."""
+    import ctypes as C
+    cfg = pkg.make_config(name, max_seq_len=192)
+    model = pkg.SynthModel(cfg, mix=mix)
+    full = pkg.HipGpuInference.from_model(model, 192)
+    s0 = pkg.HipGpuInference.from_model(model, 192, layer_range=(0, split))
+    s1 = pkg.HipGpuInference.from_model(model, 192, layer_range=(split, cfg.num_layers))
+    assert s0.prefill_is_batched() and s1.prefill_is_batched()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    prompt = [(5 * i + 2) % cfg.vocab_size for i in range(150)]
+    full.forward_batch(prompt)
+    for i in range(0, len(prompt), 128):
+        chunk = prompt[i:i + 128]
+        s0.stage_prefill_batch(chunk, len(chunk))
+        s0.synchronize()
+        assert hip.hipMemcpy(s1.stage_hidden_block_ptr(), s0.stage_hidden_block_ptr(), len(chunk) * cfg.hidden_size * 4, 3) == 0  # D2D
+        assert hip.hipDeviceSynchronize() == 0                   # a device-to-device hipMemcpy may return before it is done
+        s1.stage_prefill_batch(None, len(chunk))
+        s1.synchronize()                                         # the next block overwrites s1's input block (own stream)
+    assert s0.position() == s1.position() == full.position() == 150
+    for tok in (3, 4, 5):
+        want = full.forward(tok)
+        s0.stage_forward(tok)
+        s0.synchronize()
+        assert hip.hipMemcpy(s1.stage_hidden_ptr(), s0.stage_hidden_ptr(), cfg.hidden_size * 4, 3) == 0
+        assert hip.hipDeviceSynchronize() == 0
+        got = s1.stage_forward(0, want_logits=True)
+        assert np.array_equal(got, want)
+    with pytest.raises(pkg.BackendError):
+        s0.stage_prefill_batch(list(range(129)), 129)            # a block holds at most 128 tokens
+    with pytest.raises(pkg.BackendError):
+        s0.stage_prefill_batch(None, 4)                          # the first stage needs the ids
+    for e in (full, s0, s1):
+        e.close()
