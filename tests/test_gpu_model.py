@@ -333,3 +333,17 @@ def test_kv_shift_left_and_truncate_follow_the_reference_cache(pkg, orc):
     eng.kv_shift_left(100)                                # more than there is: cleared
     assert eng.position() == 0
     eng.close()
+
+
+def test_stage_contexts_decode_correctly_in_a_fresh_process():
+    """Every rank of a real multi-GPU run is a fresh process.  A kernel first launched inside a hipGraph capture was not
+    replayed with the graph (ROCm 7.0), which only stages behind the first exposed — and only in a fresh process, so no
+    in-process test could see it.  `lgh_finalize` now warms the kernels; this runs the reproduction in a subprocess."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for args in (("0", "1", "5"), ("255", "2", "9")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_stage_first_capture.py"), *args], check=True,
+                             capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+        assert out and out[-1].startswith("rep 0") and out[-1].endswith("max|d|=0.000e+00"), out
