@@ -276,7 +276,12 @@ def run_pipeline(args, pkg):
     stage = pkg.pipeline.HipStage(eng, torch, dev)
     dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
-    dec.prefill(prompt[:-1])                           # blocks of hidden vectors per hop where the stages have the batched path
+    # blocks of hidden vectors per hop only when EVERY stage has the batched prompt path (the hop protocol must agree)
+    agree = torch.tensor([1 if getattr(stage, "block_tokens", 0) else 0], device=dev, dtype=torch.int32)
+    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    if int(agree.item()) == 0:
+        stage.block_tokens = 0
+    dec.prefill(prompt[:-1])
     dec.step(prompt[-1])
     tok = prompt[-1]
     for _ in range(W):

@@ -208,6 +208,19 @@ hipError_t attn_generic_launch(const float* q, const float* k, const float* v, f
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
 
+// The opt-in to more than 64 KB of dynamic LDS is per kernel AND per device: `done` is that kernel's per-device record
+// (a process may drive several GPUs: two stage contexts, a test creating contexts on different devices).
+inline hipError_t lds_opt_in(const void* fn, int bytes, bool (&done)[64]) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  if (done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[dev] = true;
+  return e;
+}
+
 // device state block: [0] token, [1] current position, [2] next position, [3] last arg-max
 enum { ST_TOKEN = 0, ST_POS = 1, ST_NEXT = 2, ST_ARGMAX = 3, ST_WORDS = 8 };
 

@@ -578,13 +578,8 @@ int mv_symbol(const MvLaunch& L) {
 
 template <uint32_t MASK, int MAXT>
 static hipError_t mv_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st) {
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in once per kernel
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mv_kernel<MASK, MAXT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static bool attr_set[64] = {};  // > 64 KB of dynamic LDS needs the opt-in once per kernel and device
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mv_kernel<MASK, MAXT>), 160 * 1024, attr_set); e != hipSuccess) return e;
   if (threads > (uint32_t)MAXT) return hipErrorInvalidValue;
   hipLaunchKernelGGL((mv_kernel<MASK, MAXT>), dim3(n_wg), dim3(threads), lds, st, L);
   return hipGetLastError();

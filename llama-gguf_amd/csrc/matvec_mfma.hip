@@ -808,12 +808,8 @@ size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
 template <uint32_t MASK>
 static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
                          uint32_t geom2, uint32_t red_off) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static bool attr_set[64] = {};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_kernel<MASK>), 160 * 1024, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL((mvq_kernel<MASK>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
   return hipGetLastError();
 }
@@ -885,12 +881,8 @@ hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uin
 
 template <uint32_t MASK>
 static hipError_t chain_go(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mvq_chain_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static bool attr_set[64] = {};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_chain_kernel<MASK>), 160 * 1024, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL((mvq_chain_kernel<MASK>), dim3(kNumCU), dim3(h.threads), h.lds, st, dev_ops, dev_geo, h.nops, sync);
   return hipGetLastError();
 }

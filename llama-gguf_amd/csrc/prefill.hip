@@ -301,13 +301,9 @@ __global__ void __launch_bounds__(kPfWaves * 64) pf_gemm_kernel(const PfGemm G) 
 
 template <uint32_t MASK>
 static hipError_t pf_gemm_go(const PfGemm& G, uint32_t n_rg, hipStream_t st) {
-  static bool attr_set = false;
+  static bool attr_set[64] = {};
   constexpr size_t lds = 2 * kPfSlabBytes;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pf_gemm_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&pf_gemm_kernel<MASK>), (int)lds, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL((pf_gemm_kernel<MASK>), dim3(n_rg, G.S), dim3(kPfWaves * 64), lds, st, G);
   return hipGetLastError();
 }
