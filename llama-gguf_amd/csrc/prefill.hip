@@ -52,8 +52,14 @@ static int pf_fmt_of(int dev_type) {
          : dev_type == kDevQ80_T16 ? PF_Q80 : dev_type == kDevQ40_T16 ? PF_Q40 : -1;
 }
 
-constexpr int kPfRT = 4;                 // row tiles per wave
-constexpr int kPfWaves = 4;
+// waves per workgroup: 4 (one per SIMD, 4 row tiles each).  8 waves of 2 tiles (-DPF_WAVES=8: two per SIMD, twice the LDS
+// reads per MFMA) measured the same 4.68 ms per 128-token Llama-3-8B prompt: the loop is not latency-bound.
+#ifndef PF_WAVES
+#define PF_WAVES 4
+#endif
+constexpr int kPfWaves = PF_WAVES;
+constexpr int kPfRT = 16 / kPfWaves;     // row tiles per wave (a workgroup covers 256 rows)
+constexpr uint32_t kPfDmaBytes = kPfSlabBytes / kPfWaves;   // a wave's share of a slab
 constexpr int kPfMT = kPfTokens / 16;    // token tiles
 constexpr float kPfScale = 256.0f;
 
@@ -202,10 +208,10 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
 
   // one 64 KB slab -> LDS buffer `buf`: this wave's quarter, 16 x 1 KB by LDS-DMA (no registers)
   auto x_dma = [&](uint32_t b, uint32_t buf) {
-    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * 16384 + lane * 16;
-    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * 16384;
+    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * kPfDmaBytes + lane * 16;
+    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * kPfDmaBytes;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int i = 0; i < (int)(kPfDmaBytes / 1024); i++) {
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src + i * 1024), "s"(dst + i * 1024) : "memory");
