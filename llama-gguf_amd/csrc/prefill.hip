@@ -40,7 +40,6 @@ namespace lgh {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // formats as in matvec_mfma.hip (same tile16 layouts)
 enum : int { PF_Q4K = 0, PF_Q6K = 1, PF_Q5K = 2, PF_Q80 = 3, PF_Q40 = 4 };

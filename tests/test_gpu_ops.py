@@ -158,3 +158,16 @@ def test_silu_mul(gpu, orc):
     g, u = rng.standard_normal(5000).astype(np.float32) * 4, rng.standard_normal(5000).astype(np.float32)
     want, got = orc.silu_mul(g, u), gpu.op_silu_mul(g, u)
     assert np.abs(got - want).max() <= 4e-7 * (1 + np.abs(want).max())
+
+
+@pytest.mark.parametrize("tname", ["Q8_1", "Q8_K"])
+def test_dequantize_activation_formats_bit_exact(gpu, orc, tname):
+    """Q8_1 / Q8_K (blocks.rs:8-168; dequant.rs:117-123, 361-367) have no synthetic weight generator — they are the
+    reference's activation formats — so the blocks come from the oracle's own quantizer."""
+    t = getattr(orc, tname)
+    x = (np.random.default_rng(5).standard_normal(256 * 9) * 3).astype(np.float32)
+    raw = orc.quantize(t, x)
+    want = orc.dequantize(t, raw, x.size)
+    got = gpu.op_dequantize(t, raw, x.size)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.abs(want - x).max() < 0.1                               # and the round trip is what the reference's bounds say
