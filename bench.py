@@ -142,7 +142,8 @@ def run_single(args, pkg):
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
-    eng.forward_batch(prompt[:-1])
+    for t in prompt[:-1]:                                              # the exact (f32) prompt path: the decode that is timed
+        eng.prefill_token(t)                                           # starts from the cache the CPU reference would have
     eng.forward(prompt[-1])                                           # prefill = Model::forward(prompt) (main.rs:1804-1807)
     warm = eng.decode_greedy(prompt[-1], W) if W > 0 else np.array([prompt[-1]], np.uint32)  # main.rs:1812-1822
     tok = int(warm[-1])
@@ -190,10 +191,11 @@ def run_single(args, pkg):
                    "token_by_token_tokens_per_s": round((len(prompt) - 1) / seq_s, 1),
                    "roofline": {"bound": "mfma", "achieved": round(tflops, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tflops / MFMA_F16_PEAK_TFLOPS, 4), "dtype": "f16 operands, f32 accumulation",
-                                "note": "whole prompt pass (GEMMs + attention + row kernels), dense models only"}
+                                "note": "whole prompt pass (GEMMs + attention + row kernels); flops counted for dense layers"}
                    if eng.prefill_is_batched() and not cfg.num_experts else None}
     eng.reset()
-    eng.forward_batch(prompt[:-1])
+    for t in prompt[:-1]:
+        eng.prefill_token(t)
     eng.forward(prompt[-1])
     t0 = time.perf_counter()
     t = prompt[-1]
