@@ -136,6 +136,26 @@ def test_hip_model_matches_golden(gpu, pkg, name, mix):
     eng.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mix", MODELS)
+def test_hip_batched_prompt_pass_matches_golden(gpu, pkg, name, mix):
+    """The same fixtures through `forward_batch` (the f16-GEMM prompt pass) + `forward`: the prompt's logits
+    and the steps after it within the prompt-pass tolerance 1e-2 * max|logit| + 1e-2 of the committed CPU-oracle vectors."""
+    fx = np.load(os.path.join(GOLD, f"model_{name}_{mix}_v1.npz"))
+    cfg = pkg.make_config(name, max_seq_len=64)
+    eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=mix), 64)
+    prompt = fx["prompt"].tolist()
+    eng.forward_batch(prompt[:-1])
+    feed = [prompt[-1]] + [int(t) for t in fx["tokens"][:-1]]
+    for i, tok in enumerate(feed):
+        got, want = eng.forward(tok), fx["logits"][i]
+        err = float(np.abs(got - want).max())
+        assert err <= 1e-2 * float(np.abs(want).max()) + 1e-2
+        if float(fx["top_gap"][i]) > 4 * err:
+            assert int(np.flatnonzero(got == got.max())[-1]) == int(fx["tokens"][i])
+    eng.close()
+
+
 def test_oracle_kv_shift_left_is_a_row_move(orc, pkg):
     """KVCache::shift_left (model/mod.rs:142-172): after dropping the first `amount` rows the model behaves as if the
     remaining rows had been written at positions 0.. — checked against a fresh model whose cache rows are produced the
