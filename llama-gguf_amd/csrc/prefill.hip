@@ -58,8 +58,7 @@ static int pf_fmt_of(int dev_type) {
 #endif
 constexpr int kPfWaves = PF_WAVES;
 constexpr int kPfRT = 16 / kPfWaves;     // row tiles per wave (a workgroup covers 256 rows)
-constexpr uint32_t kPfDmaBytes = kPfSlabBytes / kPfWaves;   // a wave's share of a slab
-constexpr int kPfMT = kPfTokens / 16;    // token tiles
+constexpr int kPfMT = kPfTokens / 16;    // token tiles of a full block
 constexpr float kPfScale = 256.0f;
 
 struct PfRaw { u32x4 hd; u32x4 q[4]; };
@@ -176,14 +175,11 @@ __device__ __forceinline__ h16x8 pf_frag(const PfRaw& r, int pp, int h, h16x2 S,
   return pf_frag_bytes(B0, B1, S, O);
 }
 
-template <int F>
-__device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32_t rg, uint32_t ks, uint8_t* smem) {
-  uint32_t m_tiles = G.m_tiles;
-  if (G.m_count) {   // MoE: this expert's row count lives on the device (no host round trip per layer)
-    const uint32_t cnt = (uint32_t)*G.m_count;
-    if (cnt == 0) return;
-    m_tiles = (cnt + 15) / 16;
-  }
+// MT = token tiles computed: 8 for a full block, 4 / 2 when at most 64 / 32 rows are real (short prompts, and the rows routed
+// to one MoE expert — about 32 of 128 with 2-of-8 routing): the MFMAs, the LDS reads and the activation DMA shrink with it.
+template <int F, int MT>
+__device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32_t rg, uint32_t ks, uint32_t m_tiles, uint8_t* smem) {
+  constexpr uint32_t kDma = (uint32_t)MT * 16 * 512 / kPfWaves;   // a wave's share of the MT * 16 rows of a slab that are copied
   const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t n = lane & 15, c = lane >> 4;
   constexpr uint32_t tb = pf_tile_bytes(F);
@@ -199,18 +195,18 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
 
-  f32x4 acc[kPfRT][kPfMT];
+  f32x4 acc[kPfRT][MT];
 #pragma unroll
   for (int r = 0; r < kPfRT; r++)
 #pragma unroll
-    for (int t = 0; t < kPfMT; t++) acc[r][t] = (f32x4)(0.0f);
+    for (int t = 0; t < MT; t++) acc[r][t] = (f32x4)(0.0f);
 
   // one 64 KB slab -> LDS buffer `buf`: this wave's quarter, 16 x 1 KB by LDS-DMA (no registers)
   auto x_dma = [&](uint32_t b, uint32_t buf) {
-    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * kPfDmaBytes + lane * 16;
-    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * kPfDmaBytes;
+    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * kDma + lane * 16;
+    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * kDma;
 #pragma unroll
-    for (int i = 0; i < (int)(kPfDmaBytes / 1024); i++) {
+    for (int i = 0; i < (int)(kDma / 1024); i++) {
       uint32_t keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src + i * 1024), "s"(dst + i * 1024) : "memory");
@@ -243,12 +239,12 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     // port for 8 cycles and each of the ~2.7 VALU ops per MFMA for 4 more, so the loop is VALU-issue-bound; forcing an
     // MFMA / VALU interleave with sched_group_barrier changed nothing (4.94 vs 4.88 ms).
     const uint8_t* xb = smem + cur * kPfSlabBytes + n * 512;
-    h16x8 bf[2][kPfMT];
+    h16x8 bf[2][MT];
     h16x2 S[kPfRT], O[kPfRT];
     auto read_bf = [&](int ph, h16x8* dst) {
       const uint32_t q = (uint32_t)((ph >> 1) * 8 + (ph & 1)) + c * 2;
 #pragma unroll
-      for (int t = 0; t < kPfMT; t++) dst[t] = *reinterpret_cast<const h16x8*>(xb + t * 8192 + ((q ^ n) << 4));
+      for (int t = 0; t < MT; t++) dst[t] = *reinterpret_cast<const h16x8*>(xb + t * 8192 + ((q ^ n) << 4));
     };
     read_bf(0, bf[0]);
     pf_scale<F>(w[0], 0, n, c, S[0], O[0]);
@@ -264,7 +260,7 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
         af[(u + 1) & 1] = pf_frag<F>(w[r2], pp2, h2, S[r2], O[r2]);
       }
 #pragma unroll
-      for (int t = 0; t < kPfMT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1], bf[ph & 1][t], acc[r][t], 0, 0, 0);
+      for (int t = 0; t < MT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1], bf[ph & 1][t], acc[r][t], 0, 0, 0);
       const bool rd = r == 0 && ph + 1 < 8;
       if (rd) read_bf(ph + 1, bf[(ph + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
@@ -279,7 +275,7 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     if (tile0 + r >= sg.ntiles) continue;
     const uint32_t col = sg.col0 + (tile0 + r) * 16 + c * 4;
 #pragma unroll
-    for (int t = 0; t < kPfMT; t++) {
+    for (int t = 0; t < MT; t++) {
       if ((uint32_t)t >= m_tiles) continue;
       const f32x4 v = acc[r][t] * (1.0f / kPfScale);
       *reinterpret_cast<f32x4*>(part + (size_t)(t * 16 + n) * G.ncols + col) = v;
@@ -297,11 +293,25 @@ __global__ void __launch_bounds__(kPfWaves * 64) pf_gemm_kernel(const PfGemm G) 
   const PfSeg& sg = G.seg[si];
   const uint32_t rg = rgid - sg.rg_begin;
   auto is = [&](int f) { return (MASK & (1u << f)) && (MASK == (1u << f) || sg.fmt == f); };
-  if (is(PF_Q4K)) pf_body<PF_Q4K>(G, sg, rg, blockIdx.y, pf_smem);
-  else if (is(PF_Q6K)) pf_body<PF_Q6K>(G, sg, rg, blockIdx.y, pf_smem);
-  else if (is(PF_Q5K)) pf_body<PF_Q5K>(G, sg, rg, blockIdx.y, pf_smem);
-  else if (is(PF_Q80)) pf_body<PF_Q80>(G, sg, rg, blockIdx.y, pf_smem);
-  else if (is(PF_Q40)) pf_body<PF_Q40>(G, sg, rg, blockIdx.y, pf_smem);
+  uint32_t m_tiles = G.m_tiles;
+  if (G.m_count) {   // MoE: this expert's row count lives on the device (no host round trip per layer)
+    uint32_t cnt;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cnt) : "s"(G.m_count) : "memory");
+    if (cnt == 0) return;
+    m_tiles = (cnt + 15) / 16;
+  }
+#define LGH_PF_RUN(F)                                                                    \
+  do {                                                                                   \
+    if (m_tiles <= 2) pf_body<F, 2>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);            \
+    else if (m_tiles <= 4) pf_body<F, 4>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);       \
+    else pf_body<F, kPfMT>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);                     \
+  } while (0)
+  if (is(PF_Q4K)) LGH_PF_RUN(PF_Q4K);
+  else if (is(PF_Q6K)) LGH_PF_RUN(PF_Q6K);
+  else if (is(PF_Q5K)) LGH_PF_RUN(PF_Q5K);
+  else if (is(PF_Q80)) LGH_PF_RUN(PF_Q80);
+  else if (is(PF_Q40)) LGH_PF_RUN(PF_Q40);
+#undef LGH_PF_RUN
 }
 
 template <uint32_t MASK>
@@ -546,20 +556,24 @@ hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* 
 // MoE layers: tokens grouped by expert so that every expert's matrices are read once per block of tokens
 // ------------------------------------------------------------------------------------------------
 // lists[e][i] = token | slot << 8 for the i-th (token, slot) routed to expert e, in token order; counts[e]
-__global__ void __launch_bounds__(64) pf_moe_group_kernel(const int* __restrict__ sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts,
-                                                          int* __restrict__ counts, int* __restrict__ lists) {
+__global__ void __launch_bounds__(256) pf_moe_group_kernel(const int* __restrict__ sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts,
+                                                           int* __restrict__ counts, int* __restrict__ lists) {
+  __shared__ int s_sel[kPfTokens * 8];
+  const uint32_t n = m_tokens * top_k;   // <= 128 * 8: the routing table in one round trip, then each expert's thread scans LDS
+  for (uint32_t i = threadIdx.x; i < n; i += 256) s_sel[i] = sel[i];
+  __syncthreads();
   const uint32_t e = threadIdx.x;
   if (e >= n_experts) return;
-  int n = 0;
+  int c = 0;
   for (uint32_t t = 0; t < m_tokens; t++)
     for (uint32_t s = 0; s < top_k; s++)
-      if ((uint32_t)sel[t * top_k + s] == e && n < kPfTokens) lists[e * kPfTokens + n++] = (int)(t | s << 8);
-  counts[e] = n;
+      if ((uint32_t)s_sel[t * top_k + s] == e && c < kPfTokens) lists[e * kPfTokens + c++] = (int)(t | s << 8);
+  counts[e] = c;
 }
 
 hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st) {
-  if (n_experts > (uint32_t)kPfMaxExperts || top_k == 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_moe_group_kernel, dim3(1), dim3(64), 0, st, sel, m_tokens, top_k, n_experts, counts, lists);
+  if (n_experts > (uint32_t)kPfMaxExperts || top_k == 0 || top_k > 8 || m_tokens > (uint32_t)kPfTokens) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_group_kernel, dim3(1), dim3(256), 0, st, sel, m_tokens, top_k, n_experts, counts, lists);
   return hipGetLastError();
 }
 
