@@ -562,13 +562,21 @@ __global__ void __launch_bounds__(256) pf_moe_group_kernel(const int* __restrict
   const uint32_t n = m_tokens * top_k;   // <= 128 * 8: the routing table in one round trip, then each expert's thread scans LDS
   for (uint32_t i = threadIdx.x; i < n; i += 256) s_sel[i] = sel[i];
   __syncthreads();
-  const uint32_t e = threadIdx.x;
-  if (e >= n_experts) return;
-  int c = 0;
-  for (uint32_t t = 0; t < m_tokens; t++)
-    for (uint32_t s = 0; s < top_k; s++)
-      if ((uint32_t)s_sel[t * top_k + s] == e && c < kPfTokens) lists[e * kPfTokens + c++] = (int)(t | s << 8);
-  counts[e] = c;
+  // one wave per expert (round-robin): 64 routing entries per step, positions by ballot + popcount — entry order
+  // (token-major) is kept.  (A thread per expert walking the table entry by entry took 30 us: 256 dependent LDS reads.)
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t e = wave; e < n_experts; e += 4) {
+    uint32_t base = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+      const uint32_t i = j0 + lane;
+      const bool hit = i < n && (uint32_t)s_sel[i] == e;
+      const unsigned long long mask = __ballot(hit);
+      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && pos < (uint32_t)kPfTokens) lists[e * kPfTokens + pos] = (int)((i / top_k) | (i % top_k) << 8);
+      base += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) counts[e] = (int)(base < (uint32_t)kPfTokens ? base : (uint32_t)kPfTokens);
+  }
 }
 
 hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st) {
