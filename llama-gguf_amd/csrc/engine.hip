@@ -767,7 +767,7 @@ static int pf_ensure(lgh_ctx* c) {
       {(void**)&P.ssq, (size_t)kPfTokens * kPfSsqChunks * 4},
       {(void**)&P.moe_sel, any_moe ? (size_t)kPfTokens * topk * 4 : 0},  {(void**)&P.moe_w, any_moe ? (size_t)kPfTokens * topk * 4 : 0},
       {(void**)&P.moe_cnt, any_moe ? (size_t)kPfMaxExperts * 4 : 0},    {(void**)&P.moe_list, any_moe ? (size_t)kPfMaxExperts * kPfTokens * 4 : 0},
-      {(void**)&P.moe_y, any_moe ? (size_t)topk * kPfTokens * H * 4 : 0}, {(void**)&P.xh_gather, any_moe ? xh_bytes(H) : 0},
+      {(void**)&P.moe_y, any_moe ? (size_t)topk * kPfTokens * H * 4 : 0}, {(void**)&P.xh_gather, any_moe ? xh_bytes(H) * d.num_experts : 0},
   };
   for (auto& b : bufs) {
     if (!b.n) continue;
@@ -835,12 +835,12 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     const uint32_t topk = d.num_experts_per_token, EI = L.gate_exps.n;
     if ((rc = K(moe_router_launch(P.hidden, L.ffn_norm, d.norm_eps, L.router, H, d.num_experts, topk, P.moe_sel, P.moe_w, st, m), "router"))) return rc;
     if ((rc = K(pf_moe_group_launch(P.moe_sel, m, topk, d.num_experts, P.moe_cnt, P.moe_list, st), "expert grouping"))) return rc;
+    if ((rc = K(pf_moe_gather_launch(P.xh_h, H, P.moe_list, P.moe_cnt, P.xh_gather, d.num_experts, st), "expert gather"))) return rc;
     for (uint32_t e = 0; e < d.num_experts; e++) {
       const int* cnt = P.moe_cnt + e;
       const int* list = P.moe_list + (size_t)e * kPfTokens;
-      if ((rc = K(pf_moe_gather_launch(P.xh_h, H, list, cnt, P.xh_gather, st), "expert gather"))) return rc;
       const DevWeight* gu[2] = {&L.gate_exps, &L.up_exps};
-      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_gather, P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert gate/up GEMM"))) return rc;
+      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_gather + (size_t)e * xh_bytes(H), P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert gate/up GEMM"))) return rc;
       if ((rc = K(pf_swiglu_launch(P.part, S, EI, P.xh_act, P.ssq, H, d.norm_eps, kPfTokens, st, list, cnt), "expert SwiGLU"))) return rc;
       const DevWeight* dn[1] = {&L.down_exps};
       if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert down GEMM"))) return rc;

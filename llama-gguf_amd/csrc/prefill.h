@@ -46,7 +46,9 @@ hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* 
 // ---- MoE layers (moe.rs:321-413), tokens grouped by expert: lists[e][i] = token | slot << 8 in token order, counts[e]
 constexpr int kPfMaxExperts = 64;
 hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st);
-hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* list, const int* count, uint8_t* xh_out, hipStream_t st);
+// rows of every expert's batch gathered in one launch: expert e's XH at xh_out + e * xh_bytes(K)
+hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* lists, const int* counts, uint8_t* xh_out, uint32_t n_experts,
+                                hipStream_t st);
 hipError_t pf_moe_down_epi_launch(const float* part, uint32_t S, uint32_t H, const int* list, const int* count, float* y, hipStream_t st);
 hipError_t pf_to_xh_launch(const float* x, uint32_t K, uint8_t* xh, uint32_t m_tokens, hipStream_t st);
 // dequant.hip: rows tokens[0..m) of the embedding table -> dst[m][hidden]

@@ -586,18 +586,23 @@ hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k
 }
 
 // row i of the expert's XH batch = the XH row of token list[i] (the chunk swizzle depends on the row index: re-swizzled)
+// (all experts in one launch: blockIdx.z = expert, its list / count / output at stride kPfTokens / 1 / out_stride)
 __global__ void __launch_bounds__(256) pf_moe_gather_kernel(const uint8_t* __restrict__ xh, const int* __restrict__ list, const int* __restrict__ count,
-                                                            uint8_t* __restrict__ xh_out) {
+                                                            uint8_t* __restrict__ xh_out, size_t out_stride) {
   const uint32_t slab = blockIdx.x, i = blockIdx.y * 8 + (threadIdx.x >> 5), q = threadIdx.x & 31;
+  list += blockIdx.z * kPfTokens;
+  count += blockIdx.z;
+  xh_out += blockIdx.z * out_stride;
   if (i >= (uint32_t)*count) return;
   const uint32_t ts = (uint32_t)list[i] & 0xFFu;
   const u32x4 v = *reinterpret_cast<const u32x4*>(xh + (size_t)slab * kPfSlabBytes + ts * 512 + ((q ^ (ts & 15)) << 4));
   *reinterpret_cast<u32x4*>(xh_out + (size_t)slab * kPfSlabBytes + i * 512 + ((q ^ (i & 15)) << 4)) = v;
 }
 
-hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* list, const int* count, uint8_t* xh_out, hipStream_t st) {
-  if (K % 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_moe_gather_kernel, dim3(K / 256, kPfTokens / 8), dim3(256), 0, st, xh, list, count, xh_out);
+hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* lists, const int* counts, uint8_t* xh_out, uint32_t n_experts,
+                                hipStream_t st) {
+  if (K % 256 || n_experts == 0 || n_experts > (uint32_t)kPfMaxExperts) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_gather_kernel, dim3(K / 256, kPfTokens / 8, n_experts), dim3(256), 0, st, xh, lists, counts, xh_out, xh_bytes(K));
   return hipGetLastError();
 }
 
