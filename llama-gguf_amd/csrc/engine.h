@@ -38,9 +38,9 @@ struct PfScratch {
   size_t part_bytes = 0;
   int* tokens = nullptr;
   // MoE layers: routing of the block's tokens, tokens grouped by expert, one expert's gathered input, per-slot expert outputs
-  int *moe_sel = nullptr, *moe_cnt = nullptr, *moe_list = nullptr;
-  float *moe_w = nullptr, *moe_y = nullptr;
-  uint8_t* xh_gather = nullptr;
+  int *moe_sel = nullptr, *moe_cnt = nullptr, *moe_base = nullptr, *moe_list = nullptr, *moe_rowmap = nullptr, *moe_tokmap = nullptr;
+  float* moe_w = nullptr;
+  uint8_t *xh_gather = nullptr, *xh_act_e = nullptr;   // per expert: gathered inputs [E][xh_bytes(H)], activations [E][xh_bytes(EI)]
 };
 
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };

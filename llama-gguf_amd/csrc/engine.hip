@@ -731,7 +731,9 @@ static bool pf_eligible(const lgh_ctx* c) {
     for (const DevWeight* W : {&L.wq, &L.wk, &L.wv, &L.wo})
       if (!pf_supported_type(W->type) || W->n % 16) return false;
     if (L.moe()) {   // experts: tokens are grouped by expert (prefill.hip); up to 8 selected, at most 64 experts
-      if (d.num_experts > (uint32_t)kPfMaxExperts || d.num_experts_per_token == 0 || d.num_experts_per_token > 8) return false;
+      if (d.num_experts > (uint32_t)kPfMaxExperts || d.num_experts_per_token == 0 || d.num_experts_per_token > (uint32_t)kPfMaxTopK ||
+          (uint32_t)kPfTokens * d.num_experts_per_token + 15 * d.num_experts > (uint32_t)kPfMoeRows)
+        return false;
       for (const DevWeight* W : {&L.gate_exps, &L.up_exps, &L.down_exps})
         if (!pf_supported_type(W->type) || W->n % 16 || W->k % 256) return false;
     } else {
@@ -756,7 +758,7 @@ static int pf_ensure(lgh_ctx* c) {
   size_t pb = pf_part_bytes(qkv, 3, H);
   pb = std::max(pb, pf_part_bytes(one, 1, QD));
   if (F) { const uint32_t gu[2] = {F, F}; pb = std::max({pb, pf_part_bytes(gu, 2, H), pf_part_bytes(one, 1, F)}); }
-  if (EI) { const uint32_t gu[2] = {EI, EI}; pb = std::max({pb, pf_part_bytes(gu, 2, H), pf_part_bytes(one, 1, EI)}); }
+  if (EI) { const uint32_t gu[2] = {EI, EI}; pb = std::max({pb, pf_part_bytes(gu, 2, H, kPfMoeRows), pf_part_bytes(one, 1, EI, kPfMoeRows)}); }
   const uint32_t topk = d.num_experts_per_token ? d.num_experts_per_token : 1;
   int rc;
   struct { void** p; size_t n; } bufs[] = {
@@ -767,7 +769,9 @@ static int pf_ensure(lgh_ctx* c) {
       {(void**)&P.ssq, (size_t)kPfTokens * kPfSsqChunks * 4},
       {(void**)&P.moe_sel, any_moe ? (size_t)kPfTokens * topk * 4 : 0},  {(void**)&P.moe_w, any_moe ? (size_t)kPfTokens * topk * 4 : 0},
       {(void**)&P.moe_cnt, any_moe ? (size_t)kPfMaxExperts * 4 : 0},    {(void**)&P.moe_list, any_moe ? (size_t)kPfMaxExperts * kPfTokens * 4 : 0},
-      {(void**)&P.moe_y, any_moe ? (size_t)topk * kPfTokens * H * 4 : 0}, {(void**)&P.xh_gather, any_moe ? xh_bytes(H) * d.num_experts : 0},
+      {(void**)&P.moe_base, any_moe ? (size_t)kPfMaxExperts * 4 : 0},   {(void**)&P.moe_rowmap, any_moe ? (size_t)kPfMoeRows * 4 : 0},
+      {(void**)&P.moe_tokmap, any_moe ? (size_t)kPfTokens * kPfMaxTopK * 4 : 0},
+      {(void**)&P.xh_gather, any_moe ? xh_bytes(H) * d.num_experts : 0}, {(void**)&P.xh_act_e, any_moe ? xh_bytes(EI) * d.num_experts : 0},
   };
   for (auto& b : bufs) {
     if (!b.n) continue;
@@ -834,21 +838,27 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     // expert, and run each expert once over its rows: gather -> gate|up GEMM -> SwiGLU -> down GEMM -> rows back to tokens
     const uint32_t topk = d.num_experts_per_token, EI = L.gate_exps.n;
     if ((rc = K(moe_router_launch(P.hidden, L.ffn_norm, d.norm_eps, L.router, H, d.num_experts, topk, P.moe_sel, P.moe_w, st, m), "router"))) return rc;
-    if ((rc = K(pf_moe_group_launch(P.moe_sel, m, topk, d.num_experts, P.moe_cnt, P.moe_list, st), "expert grouping"))) return rc;
+    if ((rc = K(pf_moe_group_launch(P.moe_sel, m, topk, d.num_experts, P.moe_cnt, P.moe_base, P.moe_list, P.moe_rowmap, P.moe_tokmap, st), "expert grouping")))
+      return rc;
     if ((rc = K(pf_moe_gather_launch(P.xh_h, H, P.moe_list, P.moe_cnt, P.xh_gather, d.num_experts, st), "expert gather"))) return rc;
-    for (uint32_t e = 0; e < d.num_experts; e++) {
-      const int* cnt = P.moe_cnt + e;
-      const int* list = P.moe_list + (size_t)e * kPfTokens;
+    for (uint32_t e = 0; e < d.num_experts; e++) {   // every expert's gate|up over its rows, partial sums side by side in one row space
       const DevWeight* gu[2] = {&L.gate_exps, &L.up_exps};
-      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_gather + (size_t)e * xh_bytes(H), P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert gate/up GEMM"))) return rc;
-      if ((rc = K(pf_swiglu_launch(P.part, S, EI, P.xh_act, P.ssq, H, d.norm_eps, kPfTokens, st, list, cnt), "expert SwiGLU"))) return rc;
+      if ((rc = K(pf_gemm_launch(gu, 2, P.xh_gather + (size_t)e * xh_bytes(H), P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, P.moe_cnt + e, kPfMoeRows,
+                                 P.moe_base + e),
+                  "expert gate/up GEMM")))
+        return rc;
+    }
+    if ((rc = K(pf_moe_swiglu_launch(P.part, S, EI, P.xh_act_e, P.moe_rowmap, P.moe_list, P.ssq, H, d.norm_eps, st), "expert SwiGLU"))) return rc;
+    for (uint32_t e = 0; e < d.num_experts; e++) {
       const DevWeight* dn[1] = {&L.down_exps};
-      if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act, P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, cnt), "expert down GEMM"))) return rc;
-      if ((rc = K(pf_moe_down_epi_launch(P.part, S, H, list, cnt, P.moe_y, st), "expert rows to tokens"))) return rc;
+      if ((rc = K(pf_gemm_launch(dn, 1, P.xh_act_e + (size_t)e * xh_bytes(EI), P.part, P.part_bytes, kPfTokens, &S, &nc, st, e, P.moe_cnt + e, kPfMoeRows,
+                                 P.moe_base + e),
+                  "expert down GEMM")))
+        return rc;
     }
     // h += sum over the selected experts, in selection order, of routing weight * expert output (moe.rs:363-368), then the
     // next layer's input
-    if ((rc = K(pf_row_epi_launch(P.moe_y, topk, H, 0, nullptr, P.hidden, H, next_nw, next_xh, P.ssq, m, st, P.moe_w), "MoE combine"))) return rc;
+    if ((rc = K(pf_moe_combine_launch(P.part, S, P.moe_tokmap, P.moe_w, topk, P.hidden, H, next_nw, next_xh, P.ssq, m, st), "MoE combine"))) return rc;
   }
   c->pos += m;
   c->stats.tokens_processed += m;

@@ -15,8 +15,9 @@
 //   XH(attn) --GEMM wo--> partials --pf_resid (+bias, +residual)--> h, XH(h * ffn_norm), sums of squares per token
 //   XH --GEMM gate|up--> partials --pf_swiglu (x 1/rms)--> XH(act) --GEMM down--> partials --pf_resid--> h, XH(h * attn_norm')
 // MoE layers (moe.rs:321-413): the f32 decode router runs once per token of the block, the (token, slot) pairs are grouped
-// by expert, and every expert runs ONCE over its rows (gather XH rows -> gate|up GEMM -> SwiGLU -> down GEMM -> rows back
-// to y[slot][token]); pf_resid then adds routing weight * expert output in selection order and the residual.
+// by expert into one row space (prefill.h), and every expert runs ONCE over its rows: one gather launch, a gate|up GEMM per
+// expert, one SwiGLU launch, a down GEMM per expert, one combine launch (routing weight * expert output in selection order,
+// then the residual).
 // The RMSNorm's 1/rms is a per-token scalar and the GEMM is linear: XH holds h * norm_weight and the kernel that adds
 // up the GEMM's partial sums multiplies by 1/rms (from the sums of squares the producer of h left) — as in the decode path.
 //
@@ -269,7 +270,9 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     __syncthreads();
   }
   // partial sums: lane holds, per (row tile, token tile), rows 4c .. 4c+3 of token n
-  float* part = G.part + (size_t)ks * kPfTokens * G.ncols;
+  uint32_t row0 = 0;
+  if (G.row_base) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(row0) : "s"(G.row_base) : "memory");
+  float* part = G.part + ((size_t)ks * G.part_rows + row0) * G.ncols;
 #pragma unroll
   for (int r = 0; r < kPfRT; r++) {
     if (tile0 + r >= sg.ntiles) continue;
@@ -338,17 +341,18 @@ static void pf_plan(const uint32_t* n_rows, int nw, uint32_t k, uint32_t* rg_out
 }
 
 // bytes of partial sums such a GEMM writes
-size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k) {
+size_t pf_part_bytes(const uint32_t* n_rows, int nw, uint32_t k, uint32_t part_rows) {
   uint32_t rg, S, cols = 0;
   pf_plan(n_rows, nw, k, &rg, &S);
   for (int i = 0; i < nw; i++) cols += n_rows[i];
-  return (size_t)S * kPfTokens * cols * 4;
+  return (size_t)S * part_rows * cols * 4;
 }
 
 // Plans and launches one GEMM: up to 3 weight matrices that share the input XH (k elements per token), outputs side by
 // side in the partial-sum buffer.  Returns the split count through *S_out (the consumer adds that many partials).
 hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, float* part, size_t part_bytes, uint32_t m_tokens,
-                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st, uint32_t expert, const int* m_count) {
+                          uint32_t* S_out, uint32_t* ncols_out, hipStream_t st, uint32_t expert, const int* m_count, uint32_t part_rows,
+                          const int* row_base) {
   if (nw < 1 || nw > 3 || m_tokens == 0 || m_tokens > (uint32_t)kPfTokens) return hipErrorInvalidValue;
   PfGemm G{};
   const uint32_t k = W[0]->k;
@@ -376,7 +380,9 @@ hipError_t pf_gemm_launch(const DevWeight* const* W, int nw, const uint8_t* xh, 
   G.part = part;
   G.m_tiles = (m_tokens + 15) / 16;
   G.m_count = m_count;
-  if ((size_t)G.S * kPfTokens * col * 4 > part_bytes) return hipErrorInvalidValue;
+  G.part_rows = part_rows;
+  G.row_base = row_base;
+  if (part_rows < (uint32_t)kPfTokens || (size_t)G.S * part_rows * col * 4 > part_bytes) return hipErrorInvalidValue;
   *S_out = G.S;
   *ncols_out = col;
   switch (mask) {
@@ -555,33 +561,58 @@ hipError_t pf_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* 
 // ------------------------------------------------------------------------------------------------
 // MoE layers: tokens grouped by expert so that every expert's matrices are read once per block of tokens
 // ------------------------------------------------------------------------------------------------
-// lists[e][i] = token | slot << 8 for the i-th (token, slot) routed to expert e, in token order; counts[e]
+// Routing table -> per-expert row lists in ONE row space (prefill.h).  One wave per expert (round-robin): 64 routing entries per
+// step, positions by ballot + popcount, entry order (token-major) kept.  (A thread per expert walking the table entry by entry
+// took 30 us: 256 dependent LDS reads.)  Pass 0 counts, thread 0 lays out the bases (padded to 16 rows), pass 1 writes.
 __global__ void __launch_bounds__(256) pf_moe_group_kernel(const int* __restrict__ sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts,
-                                                           int* __restrict__ counts, int* __restrict__ lists) {
-  __shared__ int s_sel[kPfTokens * 8];
-  const uint32_t n = m_tokens * top_k;   // <= 128 * 8: the routing table in one round trip, then each expert's thread scans LDS
+                                                           int* __restrict__ counts, int* __restrict__ bases, int* __restrict__ lists,
+                                                           int* __restrict__ rowmap, int* __restrict__ tokmap) {
+  __shared__ int s_sel[kPfTokens * kPfMaxTopK];
+  __shared__ int s_cnt[kPfMaxExperts], s_base[kPfMaxExperts];
+  const uint32_t n = m_tokens * top_k;
   for (uint32_t i = threadIdx.x; i < n; i += 256) s_sel[i] = sel[i];
+  for (uint32_t r = threadIdx.x; r < (uint32_t)kPfMoeRows; r += 256) rowmap[r] = -1;
   __syncthreads();
-  // one wave per expert (round-robin): 64 routing entries per step, positions by ballot + popcount — entry order
-  // (token-major) is kept.  (A thread per expert walking the table entry by entry took 30 us: 256 dependent LDS reads.)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t e = wave; e < n_experts; e += 4) {
-    uint32_t base = 0;
-    for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-      const uint32_t i = j0 + lane;
-      const bool hit = i < n && (uint32_t)s_sel[i] == e;
-      const unsigned long long mask = __ballot(hit);
-      const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      if (hit && pos < (uint32_t)kPfTokens) lists[e * kPfTokens + pos] = (int)((i / top_k) | (i % top_k) << 8);
-      base += (uint32_t)__popcll(mask);
+  for (int pass = 0; pass < 2; pass++) {
+    for (uint32_t e = wave; e < n_experts; e += 4) {
+      uint32_t pos0 = 0;
+      const uint32_t base = pass ? (uint32_t)s_base[e] : 0u;
+      for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+        const uint32_t i = j0 + lane;
+        const bool hit = i < n && (uint32_t)s_sel[i] == e;
+        const unsigned long long mask = __ballot(hit);
+        const uint32_t pos = pos0 + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pass && hit && pos < (uint32_t)kPfTokens) {
+          lists[e * kPfTokens + pos] = (int)((i / top_k) | (i % top_k) << 8);
+          rowmap[base + pos] = (int)(e | pos << 8);
+          tokmap[i] = (int)(base + pos);
+        }
+        pos0 += (uint32_t)__popcll(mask);
+      }
+      if (!pass && lane == 0) s_cnt[e] = (int)(pos0 < (uint32_t)kPfTokens ? pos0 : (uint32_t)kPfTokens);
     }
-    if (lane == 0) counts[e] = (int)(base < (uint32_t)kPfTokens ? base : (uint32_t)kPfTokens);
+    __syncthreads();
+    if (!pass && threadIdx.x == 0) {
+      int b = 0;
+      for (uint32_t e = 0; e < n_experts; e++) {
+        s_base[e] = b;
+        counts[e] = s_cnt[e];
+        bases[e] = b;
+        b += (s_cnt[e] + 15) & ~15;
+      }
+    }
+    __syncthreads();
   }
 }
 
-hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* lists, hipStream_t st) {
-  if (n_experts > (uint32_t)kPfMaxExperts || top_k == 0 || top_k > 8 || m_tokens > (uint32_t)kPfTokens) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_moe_group_kernel, dim3(1), dim3(256), 0, st, sel, m_tokens, top_k, n_experts, counts, lists);
+hipError_t pf_moe_group_launch(const int* sel, uint32_t m_tokens, uint32_t top_k, uint32_t n_experts, int* counts, int* bases, int* lists,
+                               int* rowmap, int* tokmap, hipStream_t st) {
+  // rows: m * top_k real ones + up to 15 of padding per expert
+  if (n_experts > (uint32_t)kPfMaxExperts || top_k == 0 || top_k > (uint32_t)kPfMaxTopK || m_tokens > (uint32_t)kPfTokens ||
+      m_tokens * top_k + 15 * n_experts > (uint32_t)kPfMoeRows)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_group_kernel, dim3(1), dim3(256), 0, st, sel, m_tokens, top_k, n_experts, counts, bases, lists, rowmap, tokmap);
   return hipGetLastError();
 }
 
@@ -606,20 +637,84 @@ hipError_t pf_moe_gather_launch(const uint8_t* xh, uint32_t K, const int* lists,
   return hipGetLastError();
 }
 
-// the expert's down-projection rows back to their tokens: y[slot][token][:] = sum of the partial sums of row i
-__global__ void __launch_bounds__(256) pf_moe_down_epi_kernel(const float* __restrict__ part, uint32_t S, uint32_t H, const int* __restrict__ list,
-                                                              const int* __restrict__ count, float* __restrict__ y) {
-  const uint32_t i = blockIdx.y, c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i >= (uint32_t)*count || c4 >= H) return;
-  const uint32_t tok = (uint32_t)list[i] & 0xFFu, slot = (uint32_t)list[i] >> 8;
-  f32x4 a = (f32x4)(0.0f);
-  for (uint32_t s = 0; s < S; s++) a += *reinterpret_cast<const f32x4*>(part + ((size_t)s * kPfTokens + i) * H + c4);
-  *reinterpret_cast<f32x4*>(y + ((size_t)slot * kPfTokens + tok) * H + c4) = a;
+// act = silu(gate) * up (simd.rs:598-649) for the rows of ALL experts: row r of the shared row space belongs to expert
+// rowmap[r] & 0xFF, is its row rowmap[r] >> 8, and carries the 1/rms of token lists[e][i] & 0xFF
+__global__ void __launch_bounds__(256) pf_moe_swiglu_kernel(const float* __restrict__ part, uint32_t S, uint32_t F, uint8_t* __restrict__ xh_out,
+                                                            size_t out_stride, const int* __restrict__ rowmap, const int* __restrict__ lists,
+                                                            const float* __restrict__ ssq, uint32_t n_ssq, uint32_t H, float eps) {
+  const uint32_t r = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
+  const int rm = rowmap[r];
+  if (rm < 0 || ch >= F / 8) return;
+  const uint32_t e = (uint32_t)rm & 0xFFu, i = (uint32_t)rm >> 8;
+  const float inv = pf_inv_rms(ssq, n_ssq, (uint32_t)lists[e * kPfTokens + i] & 0xFFu, H, eps);
+  float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, u[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t s = 0; s < S; s++) {
+    const float* row = part + ((size_t)s * kPfMoeRows + r) * (2 * (size_t)F);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(row + ch * 8), g1 = *reinterpret_cast<const f32x4*>(row + ch * 8 + 4);
+    const f32x4 u0 = *reinterpret_cast<const f32x4*>(row + F + ch * 8), u1 = *reinterpret_cast<const f32x4*>(row + F + ch * 8 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { g[j] += g0[j]; g[4 + j] += g1[j]; u[j] += u0[j]; u[4 + j] += u1[j]; }
+  }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = silu_f(g[j] * inv) * (u[j] * inv);
+  xh_store_chunk(xh_out + e * out_stride, i, ch, v);
 }
 
-hipError_t pf_moe_down_epi_launch(const float* part, uint32_t S, uint32_t H, const int* list, const int* count, float* y, hipStream_t st) {
-  if (H % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pf_moe_down_epi_kernel, dim3((H / 4 + 255) / 256, kPfTokens), dim3(256), 0, st, part, S, H, list, count, y);
+hipError_t pf_moe_swiglu_launch(const float* part, uint32_t S, uint32_t F, uint8_t* xh_out, const int* rowmap, const int* lists,
+                                const float* ssq, uint32_t H, float eps, hipStream_t st) {
+  if (F % 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_swiglu_kernel, dim3((F / 8 + 255) / 256, kPfMoeRows), dim3(256), 0, st, part, S, F, xh_out, xh_bytes(F), rowmap, lists, ssq,
+                     pf_ssq_chunks(H), H, eps);
+  return hipGetLastError();
+}
+
+// MoeLayer::forward's tail (moe.rs:363-368) + the layer's residual for every token of the block: out = 0; out += w[s] * expert
+// output of slot s, in selection order; h += out; then the next layer's XH and sums of squares (as pf_resid_kernel).
+__global__ void __launch_bounds__(256) pf_moe_combine_kernel(const float* __restrict__ part, uint32_t S, const int* __restrict__ tokmap,
+                                                             const float* __restrict__ moe_w, uint32_t top_k, float* __restrict__ hidden, uint32_t H,
+                                                             const float* __restrict__ nw, uint8_t* __restrict__ xh, float* __restrict__ ssq) {
+  __shared__ float s_ss[4];
+  const uint32_t t = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x, i = ch * 8;
+  float ss = 0.0f;
+  if (i < H) {
+    f32x4 a0 = (f32x4)(0.0f), a1 = (f32x4)(0.0f);
+    for (uint32_t s = 0; s < top_k; s++) {
+      const uint32_t row = (uint32_t)tokmap[t * top_k + s];
+      f32x4 y0 = (f32x4)(0.0f), y1 = (f32x4)(0.0f);
+      for (uint32_t sp = 0; sp < S; sp++) {
+        const float* p = part + ((size_t)sp * kPfMoeRows + row) * H + i;
+        y0 += *reinterpret_cast<const f32x4*>(p);
+        y1 += *reinterpret_cast<const f32x4*>(p + 4);
+      }
+      const float w = moe_w[t * top_k + s];
+      a0 += y0 * w;
+      a1 += y1 * w;
+    }
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i) + a0;
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i + 4) + a1;
+    *reinterpret_cast<f32x4*>(hidden + (size_t)t * H + i) = v0;
+    *reinterpret_cast<f32x4*>(hidden + (size_t)t * H + i + 4) = v1;
+    const f32x4 q = v0 * v0 + v1 * v1;
+    ss = (q.x + q.y) + (q.z + q.w);
+    if (xh) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(nw + i), w1 = *reinterpret_cast<const f32x4*>(nw + i + 4);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { v[j] = v0[j] * w0[j]; v[4 + j] = v1[j] * w1[j]; }
+      xh_store_chunk(xh, t, ch, v);
+    }
+  }
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) s_ss[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0 && ssq) ssq[t * kPfSsqChunks + blockIdx.x] = (s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]);
+}
+
+hipError_t pf_moe_combine_launch(const float* part, uint32_t S, const int* tokmap, const float* moe_w, uint32_t top_k, float* hidden, uint32_t H,
+                                 const float* nw, uint8_t* xh, float* ssq, uint32_t m_tokens, hipStream_t st) {
+  if (H % 8 || (xh && (!nw || !ssq)) || pf_ssq_chunks(H) > (uint32_t)kPfSsqChunks) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pf_moe_combine_kernel, dim3(pf_ssq_chunks(H), m_tokens), dim3(256), 0, st, part, S, tokmap, moe_w, top_k, hidden, H, nw, xh, ssq);
   return hipGetLastError();
 }
 
