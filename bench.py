@@ -281,8 +281,22 @@ def run_pipeline(args, pkg):
     # blocks of hidden vectors per hop only when EVERY stage has the batched prompt path (the hop protocol must agree)
     agree = torch.tensor([1 if getattr(stage, "block_tokens", 0) else 0], device=dev, dtype=torch.int32)
     dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-    if int(agree.item()) == 0:
-        stage.block_tokens = 0
+    prefill = None
+    if int(agree.item()):
+        dec.prefill(prompt[:-1])                       # first use allocates the scratch on every stage
+        eng.reset()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec.prefill(prompt[:-1])                       # the batched prompt pass: one [n][hidden] block per hop
+        torch.cuda.synchronize()
+        dist.barrier()
+        bat_s = time.perf_counter() - t0
+        prefill = {"tokens": len(prompt) - 1, "batched": True, "forward_batch_ms": round(1e3 * bat_s, 3),
+                   "forward_batch_tokens_per_s": round((len(prompt) - 1) / bat_s, 1)}
+        eng.reset()
+    # the decode that is timed starts from the exact (f32, token by token) cache, as on one GPU
+    stage.block_tokens = 0
     dec.prefill(prompt[:-1])
     dec.step(prompt[-1])
     tok = prompt[-1]
@@ -325,7 +339,7 @@ def run_pipeline(args, pkg):
                        "prompt_tokens": args.prompt},
             "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
                              "peak_GBps_one_gpu": HBM_PEAK_GBPS, "frac_of_one_gpu": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
-            "roofline": roofline, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": None, "prefill": prefill,
         }))
     eng.close()
     dist.destroy_process_group()
