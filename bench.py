@@ -120,11 +120,19 @@ def cpu_baseline(pkg, model, cfg, budget_s: float):
         if el >= budget_s or n >= 32:
             break
     isa = {1: "scalar", 2: "avx2", 3: "avx512"}[orc.get_isa()]
+    # the reference's CPU forward as it stands re-dequantizes the WHOLE embedding table on every call (llama.rs:181-193, 288):
+    # two tokens in that faithful mode, reported next to the kernel-only rate (SURVEY §8d asks for both)
+    t0 = time.perf_counter()
+    for _ in range(2):
+        tok = orc.argmax_last(ref.forward([tok], faithful_embedding=True))
+    faithful = 2 / (time.perf_counter() - t0)
     ref.close()
     return {"value": round(n / el, 4), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "faithful_embedding_value": round(faithful, 4),
             "sample": f"{n} greedy decode tokens after a 4-token prefill ({prefill_s:.1f}s, untimed), same weights, "
                       f"oracle C++ port of the reference CPU backend, kernel-only mode (embedding table dequantized "
-                      f"once, not per call), dot_f32 ISA path {isa}"}
+                      f"once, not per call), dot_f32 ISA path {isa}; faithful_embedding_value = 2 more tokens with the reference's "
+                      f"per-call dequantization of the whole embedding table (llama.rs:288)"}
 
 
 def run_single(args, pkg):
