@@ -4,6 +4,7 @@ kernel and the CPU baseline measured in the same run.
 
     python bench.py --gpus 1 --steps 128 --warmup 8          (default: Llama-3-8B Q4_K_M, 128-token prompt)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N   (layer pipeline)
+    python bench.py --gpus N                                  (the same: the GPU-free parent starts that launcher itself)
 
 Protocol = the reference's `llama-gguf bench` (src/main.rs:1750-1871): prompt tokens i % 32000, prefill, then
 greedy decode feeding back the arg-max (last-max tie rule).  A "step" is one decoded token.  Weights are
@@ -42,7 +43,26 @@ def committed_traffic(kernel):
     return None, None
 
 
+def traffic_age(table_name):
+    """Which profile the PMC table came from and at which commit it was collected (profiles/<tag>_meta.json, written by
+    tools/summarize_profiles.py), so that a stale table is visible in the bench line."""
+    if not table_name:
+        return None
+    tag = table_name.split("_pmc_traffic")[0]
+    meta = Path(__file__).resolve().parent / "profiles" / f"{tag}_meta.json"
+    out = {"profile": tag}
+    if meta.exists():
+        try:
+            out.update(json.loads(meta.read_text()))
+        except ValueError:
+            pass
+    return out
+
+
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense f16/bf16 (MI355X_MICROARCH.md)
+# activations, accumulation and every epilogue are f32 as in the reference; the quantized mat-vec feeds the int8 matrix cores
+# with x split exactly into four int8 limbs per element (csrc/xq.h) — a documented deviation from "wavefront reductions"
+DTYPE_LABEL = "f32 (x as 4xint8 limbs on the matrix cores, exact int32 accumulation)"
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6290 GB/s is the measured copy rate
 
 
@@ -71,6 +91,7 @@ def roofline_from_stats(st, P, step_us):
     traffic, traffic_src = committed_traffic(dom)
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_age": traffic_age(traffic_src),
             "launches_per_step": d["launches"] / P, "avg_launch_us": round(avg_us, 3),
             "kernel_only_us": round(kernel_only_us, 3), "dispatch_gap_us": round(gap_us, 3),
             "avg_launch_us_with_event_bracket": round(raw_us, 3), "event_bracket_us": round(bracket_us, 3),
@@ -89,6 +110,10 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=16, help="steps of the eager hipEvent pass (0 disables)")
     ap.add_argument("--attn-splits", type=int, default=0)
     ap.add_argument("--attn-direct", type=int, default=0, help="single-launch decode attention up to 64*n rows (0 = default, 255 = never)")
+    ap.add_argument("--reps", type=int, default=3, help="timed repetitions of the K-step region (SURVEY.md §8d: 1 warm-up + 3, mean and min)")
+    ap.add_argument("--flags", type=int, default=0, help="extra LGH_FLAG_* bits for the engine context")
+    ap.add_argument("--fake-stage", action="store_true",
+                    help="CPU rehearsal of the N>1 launcher and hop protocol: gloo + pipeline.FakeStage, no GPU, no engine (not a measurement)")
     return ap.parse_args()
 
 
@@ -146,7 +171,8 @@ def run_single(args, pkg):
     want_cpu = args.cpu_seconds > 0
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
-    eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct)
+    eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct,
+                                         flags=args.flags)
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
@@ -156,14 +182,23 @@ def run_single(args, pkg):
     warm = eng.decode_greedy(prompt[-1], W) if W > 0 else np.array([prompt[-1]], np.uint32)  # main.rs:1812-1822
     tok = int(warm[-1])
     kv0 = eng.position()
-    # ---- timed region: exactly K decode steps, device-resident token feedback
-    torch.cuda.synchronize()
-    eng.synchronize()
-    t0 = time.perf_counter()
-    toks = eng.decode_greedy(tok, K)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region (SURVEY.md §8d protocol): W warm-up steps above, then `reps` repetitions of EXACTLY K decode steps,
+    # every repetition from the same cache state (the rows past kv0 are forgotten in between, so each one decodes the same K
+    # tokens at kv_len kv0+1..kv0+K); device-resident token feedback; `value` is the mean, the best repetition is reported too
+    rep_s, toks = [], None
+    for _ in range(max(args.reps, 1)):
+        eng.kv_truncate(kv0)
+        torch.cuda.synchronize()
+        eng.synchronize()
+        t0 = time.perf_counter()
+        toks_r = eng.decode_greedy(tok, K)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t0)
+        if toks is not None and not np.array_equal(toks, toks_r):
+            raise SystemExit("bench.py: repetitions decoded different tokens (the engine must be deterministic)")
+        toks = toks_r
+    elapsed = sum(rep_s) / len(rep_s)
     kv1 = eng.position()
     tok_s = K / elapsed
     mean_kv = (kv0 + 1 + kv1) / 2.0
@@ -240,7 +275,10 @@ def run_single(args, pkg):
                   else f"decode tokens/sec {args.model} {args.mix}, 1 GPU; % of HBM roofline",
         "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": 1, "steps": K, "warmup": W,
         "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE_LABEL, "data": "synthetic",
+        "repetitions": {"n": len(rep_s), "ms_per_step": [round(1e3 * r / K, 4) for r in rep_s],
+                        "min_ms_per_step": round(1e3 * min(rep_s) / K, 4), "best_value": round(K / min(rep_s), 2),
+                        "protocol": "W warm-up steps, then n repetitions of exactly K steps from the same cache state; value = K / mean"},
         "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, seq_len=1, {args.prompt}-token prompt "
                                f"prefilled, kv_len {kv0 + 1}..{kv1}", "quant_mix": args.mix, "prompt_tokens": args.prompt,
                    "parallelism": "single GPU", "weights": "random-init synthetic blocks (SURVEY.md §8d)"},
@@ -268,93 +306,151 @@ class _Keep:
 
 
 def run_pipeline(args, pkg):
-    """N > 1: layers pipeline-sharded over N GPUs, one process per GPU, hidden vector hopped with RCCL send/recv."""
+    """N > 1: layers pipeline-sharded over N GPUs, one process per GPU.  Per token and stage boundary one f32[hidden] vector
+    goes device to device with RCCL send/recv over xGMI, and the last stage's arg-max word goes straight into the first
+    stage's token word the same way (PipelineDecoder.decode_device): no host value crosses a stage boundary per token, the
+    host only enqueues.  `--fake-stage`: the same launcher, process group and protocol on CPU (gloo, pipeline.FakeStage)."""
     import torch
     import torch.distributed as dist
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))   # unset: the 1-rank rehearsal
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     local = int(os.environ.get("LOCAL_RANK", rank))
-    assert world == args.gpus, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or os.environ.get("LGH_BENCH_FORCE_PIPELINE"), f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    fake = args.fake_stage
     W, K = args.warmup, args.steps
-    max_seq = max(512, args.prompt + W + K + min(args.profile_steps, 8) + 16)
-    cfg = pkg.make_config(args.model, max_seq_len=max_seq)
-    model = pkg.SynthModel(cfg, mix=args.mix)
-    lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
-    eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits, attn_direct=args.attn_direct)
-    stage = pkg.pipeline.HipStage(eng, torch, dev)
+    reps = max(args.reps, 1)
+    if fake:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sync = lambda: None
+        n_layers = 8
+        lo, hi = pkg.pipeline.split_layers(n_layers, world)[rank]
+        stage = pkg.pipeline.FakeStage(lo, hi, rank == 0)
+        eng = model = cfg = None
+        vocab = stage.VOCAB
+        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], dtype=torch.float64))
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+        sync = torch.cuda.synchronize
+        max_seq = max(512, args.prompt + W + reps * K + min(args.profile_steps, 8) + 16)
+        cfg = pkg.make_config(args.model, max_seq_len=max_seq)
+        model = pkg.SynthModel(cfg, mix=args.mix)
+        lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
+        eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits,
+                                             attn_direct=args.attn_direct, flags=args.flags)
+        stage = pkg.pipeline.HipStage(eng, torch, dev)
+        vocab = cfg.vocab_size
+        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], device=dev, dtype=torch.float64))
     dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
-    prompt = prompt_tokens(args.prompt, cfg.vocab_size)
-    # blocks of hidden vectors per hop only when EVERY stage has the batched prompt path (the hop protocol must agree)
-    agree = torch.tensor([1 if getattr(stage, "block_tokens", 0) else 0], device=dev, dtype=torch.int32)
-    dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+    prompt = prompt_tokens(args.prompt, vocab)
     prefill = None
-    if int(agree.item()):
-        dec.prefill(prompt[:-1])                       # first use allocates the scratch on every stage
-        eng.reset()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dec.prefill(prompt[:-1])                       # the batched prompt pass: one [n][hidden] block per hop
-        torch.cuda.synchronize()
-        dist.barrier()
-        bat_s = time.perf_counter() - t0
-        prefill = {"tokens": len(prompt) - 1, "batched": True, "forward_batch_ms": round(1e3 * bat_s, 3),
-                   "forward_batch_tokens_per_s": round((len(prompt) - 1) / bat_s, 1)}
-        eng.reset()
-    # the decode that is timed starts from the exact (f32, token by token) cache, as on one GPU
-    stage.block_tokens = 0
+    if not fake:
+        # blocks of hidden vectors per hop only when EVERY stage has the batched prompt path (the hop protocol must agree)
+        agree = red(1.0 if getattr(stage, "block_tokens", 0) else 0.0, dist.ReduceOp.MIN)
+        if agree > 0:
+            dec.prefill(prompt[:-1])                       # first use allocates the scratch on every stage
+            eng.reset()
+            dist.barrier()
+            sync()
+            t0 = time.perf_counter()
+            dec.prefill(prompt[:-1])                       # the batched prompt pass: one [n][hidden] block per hop
+            sync()
+            dist.barrier()
+            bat_s = time.perf_counter() - t0
+            prefill = {"tokens": len(prompt) - 1, "batched": True, "forward_batch_ms": round(1e3 * bat_s, 3),
+                       "forward_batch_tokens_per_s": round((len(prompt) - 1) / bat_s, 1)}
+            eng.reset()
+        # the decode that is timed starts from the exact (f32, token by token) cache, as on one GPU
+        stage.block_tokens = 0
     dec.prefill(prompt[:-1])
-    dec.step(prompt[-1])
-    tok = prompt[-1]
-    for _ in range(W):
-        tok = dec.step(tok)
-    kv0 = eng.position()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(K):
-        tok = dec.step(tok)
-    torch.cuda.synchronize()
-    dist.barrier()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kv1 = eng.position()
+    dec.decode_device(prompt[-1], 1 + W, collect=False)   # the prompt's last token + W warm-up steps; the next token stays on device
+    kv0 = stage.position()
+    rep_s = []
+    for _ in range(reps):                                  # each repetition: exactly K steps, barrier + device sync on both sides
+        sync()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dec.decode_device(None, K, collect=False)
+        sync()
+        dist.barrier()
+        rep_s.append(red(time.perf_counter() - t0, dist.ReduceOp.MAX))   # the slowest rank's clock
+    kv1 = stage.position()
+    elapsed = sum(rep_s) / len(rep_s)
     roofline = None
-    P = min(args.profile_steps, 8)
+    P = 0 if fake else min(args.profile_steps, 8)
     if P > 0:   # eager pass with a hipEvent pair around every launch; every rank takes part, rank 0 reports its stage
         eng.set_profiling(True)
-        for _ in range(P):
-            tok = dec.step(tok)
+        dec.decode_device(None, P, collect=False)
         eng.set_profiling(False)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         if rank == 0:
             roofline = roofline_from_stats(eng.stats(), P, None)
             roofline["note"] = f"stage 0 of {world} (layers {lo}..{hi - 1}); kernel-only time, no dispatch gap added"
     if rank == 0:
         tok_s = K / elapsed
-        step_bytes = model.step_alg_bytes(int(round((kv0 + 1 + kv1) / 2)))
+        name = "fake-stage" if fake else f"{args.model} {args.mix}"
+        step_bytes = 0 if fake else model.step_alg_bytes(int(round((kv0 + 1 + kv0 + K) / 2)))
         print(json.dumps({
-            "metric": f"decode tokens/sec {args.model} {args.mix}, {world} GPUs (layer pipeline); % of HBM roofline",
+            "metric": f"decode tokens/sec {name}, {world} GPUs (layer pipeline); % of HBM roofline",
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, kv_len {kv0 + 1}..{kv1}",
-                       "parallelism": f"pp{world} (contiguous layer ranges, f32[hidden] hop per stage over RCCL send/recv)",
+            "vs_baseline": None, "dtype": "none (protocol rehearsal)" if fake else DTYPE_LABEL,
+            "data": "fake stage on CPU: launcher + hop protocol rehearsal, NOT a measurement" if fake else "synthetic",
+            "repetitions": {"n": len(rep_s), "ms_per_step": [round(1e3 * r / K, 4) for r in rep_s],
+                            "min_ms_per_step": round(1e3 * min(rep_s) / K, 4), "best_value": round(K / min(rep_s), 2)},
+            "config": {"workload": f"{name} single-stream greedy decode, kv_len {kv0 + 1}..{kv1}",
+                       "parallelism": f"pp{world} (contiguous layer ranges; per token one f32[hidden] hop per stage boundary and the 4-byte "
+                                      f"token fed back device to device, RCCL send/recv over xGMI; no collective)",
                        "prompt_tokens": args.prompt},
-            "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
+            "hbm_roofline": None if fake else {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
                              "peak_GBps_one_gpu": HBM_PEAK_GBPS, "frac_of_one_gpu": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
             "roofline": roofline, "cpu_baseline": None, "prefill": prefill,
         }))
-    eng.close()
+    if eng is not None:
+        eng.close()
     dist.destroy_process_group()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: this parent — which has touched no GPU, loaded no HIP
+    library and imported no torch — starts `python -m torch.distributed.run` with N ranks of this same script as a child
+    process (never an exec), relays rank 0's single JSON line and returns the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank child run failed with status {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: the child run printed no result line", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("LGH_BENCH_FORCE_PIPELINE"):
+        sys.exit(self_launch(args))
     # ONE JSON line on stdout, nothing else: native libraries write banners to fd 1 (RCCL prints its version block there
     # at communicator creation), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
     sys.stdout.flush()

@@ -231,6 +231,17 @@ int lgh_stage_forward(lgh_ctx* ctx, uint32_t token_id, int want_logits, float* l
  * LGH_UNSUPPORTED when the context has no batched path (feed the tokens through lgh_stage_forward then). */
 int lgh_stage_prefill_batch(lgh_ctx* ctx, const uint32_t* tokens, size_t n);
 int lgh_stage_hidden_block_buffer(lgh_ctx* ctx, void** device_ptr);
+/* Token feedback WITHOUT the host (the reference's coordinator carries every token through host memory,
+ * src/distributed/pipeline.rs:50-96): *token_in = the device word the first stage embeds from, *argmax_out = the device word
+ * the last stage's arg-max lands in (int32 each).  The host side moves argmax_out -> token_in with an RCCL send/recv or a
+ * peer copy on the stages' streams. */
+int lgh_stage_io_buffers(lgh_ctx* ctx, void** token_in, void** argmax_out);
+/* lgh_stage_forward without any host value: the token is already in *token_in (first stage) / the hidden vector in the
+ * stage's hidden buffer; nothing is copied back and nothing is waited for.  mode 0 = this stage's layers only, 1 = + final
+ * norm and output projection (last stage), 2 = + device arg-max into *argmax_out and the token log (last stage). */
+int lgh_stage_step(lgh_ctx* ctx, int mode);
+/* Last stage: the arg-max tokens logged at positions [pos0, pos0 + n) (one device-to-host copy, synchronises). */
+int lgh_stage_read_tokens(lgh_ctx* ctx, size_t pos0, size_t n, uint32_t* out);
 
 /* ---- per-op surface: the `Backend` trait ops on the path (src/backend/mod.rs:29-265), host tensors
  * in / host tensors out, for parity tests of each kernel against the CPU backend. ---- */

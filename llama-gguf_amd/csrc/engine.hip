@@ -1372,4 +1372,32 @@ int lgh_stage_forward(lgh_ctx* c, uint32_t token, int want_logits, float* logits
   return LGH_OK;
 }
 
+// ---- device-side token feedback for multi-process pipelines: no host value crosses a stage boundary per token ----
+int lgh_stage_io_buffers(lgh_ctx* c, void** token_in, void** argmax_out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (token_in) *token_in = c->state + ST_TOKEN;
+  if (argmax_out) *argmax_out = c->state + ST_ARGMAX;
+  return LGH_OK;
+}
+
+int lgh_stage_step(lgh_ctx* c, int mode) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (mode < 0 || mode >= MODE_COUNT) return fail(c, LGH_INVALID_ARGUMENT, "mode must be 0 (layers only), 1 (logits) or 2 (arg-max)");
+  if (!c->last) mode = MODE_PREFILL;
+  return step(c, mode);
+}
+
+int lgh_stage_read_tokens(lgh_ctx* c, size_t pos0, size_t n, uint32_t* out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!out && n) return fail(c, LGH_INVALID_ARGUMENT, "out is NULL");
+  if (!c->last) return fail(c, LGH_INVALID_ARGUMENT, "only the last stage logs the arg-max tokens");
+  if (pos0 + n > c->d.max_seq_len) return fail(c, LGH_INVALID_ARGUMENT, "token log range exceeds max_seq_len");
+  if (n) HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(out, c->tok_log + pos0, n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return LGH_OK;
+}
+
 }  // extern "C"

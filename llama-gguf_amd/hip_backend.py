@@ -31,6 +31,7 @@ ABI_SYMBOLS = (
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
     "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
+    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
@@ -133,6 +134,8 @@ def load_library() -> C.CDLL:
         "lgh_bench_hbm_read": (C.c_int, [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]),
         "lgh_gguf_inspect": (C.c_int, [C.c_char_p, C.POINTER(GgufInfo), C.c_char_p, sz]),
         "lgh_load_gguf": (C.c_int, [C.c_char_p, u32, C.c_int, u32, u32, u32, C.POINTER(vp), C.c_char_p, sz]),
+        "lgh_stage_io_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]), "lgh_stage_step": (C.c_int, [vp, C.c_int]),
+        "lgh_stage_read_tokens": (C.c_int, [vp, sz, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -286,6 +289,22 @@ class HipGpuInference:
             self._h, token_id, int(want_logits), logits.ctypes.data if logits is not None else None,
             C.byref(nxt) if (want_logits and argmax) else None))
         return nxt.value if (want_logits and argmax) else logits
+
+    def stage_io_ptrs(self):
+        """(token_in, argmax_out): device addresses of the int32 words the first stage embeds from / the last stage's
+        arg-max lands in — the token is fed back between them without the host."""
+        a, b = C.c_void_p(), C.c_void_p()
+        self._call(load_library().lgh_stage_io_buffers(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def stage_step(self, mode: int = 0) -> None:
+        """One token through this stage with no host value in or out (0 layers only, 1 + logits, 2 + device arg-max)."""
+        self._call(load_library().lgh_stage_step(self._h, mode))
+
+    def stage_read_tokens(self, pos0: int, n: int) -> np.ndarray:
+        out = np.zeros(n, dtype=np.uint32)
+        self._call(load_library().lgh_stage_read_tokens(self._h, pos0, n, out.ctypes.data))
+        return out
 
     def set_stream(self, stream_handle: int) -> None:
         self._call(load_library().lgh_set_stream(self._h, stream_handle))

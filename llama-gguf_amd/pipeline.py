@@ -105,6 +105,48 @@ class PipelineDecoder:
             out.append(tok)
         return out
 
+    def decode_device(self, first_token, n_steps: int, collect: bool = True):
+        """`n_steps` greedy tokens with the token fed back DEVICE TO DEVICE: the last stage's arg-max word goes straight into
+        the first stage's token word (send/recv between the stages' own buffers), every stage only enqueues
+        recv -> its layers -> send on its stream, and no host value crosses a stage boundary per token (`step` above does a
+        host sync and a 4-byte device-to-host copy per boundary).  `first_token` None continues from the token the previous
+        call left in the first stage.  With `collect`, the tokens are read from the last stage's log afterwards (one sync)
+        and handed to rank 0; returns them on rank 0 and on the last rank, [] elsewhere.
+
+        `stage` must additionally provide: token_in / argmax_out (int32[1] tensors aliasing the device words),
+        set_token(t), step_async(last), position(), read_tokens(pos0, n), int_tensor(n)."""
+        st, w = self.stage, self.world
+        pos0 = st.position()
+        if self.first and first_token is not None:
+            st.set_token(int(first_token))
+        for i in range(n_steps):
+            if not self.first:
+                self.comm.recv(st.hidden, self.rank - 1)
+            elif i > 0 and w > 1:
+                self.comm.recv(st.token_in, w - 1)
+            st.step_async(self.last)
+            if not self.last:
+                self.comm.send(st.hidden, self.rank + 1)
+            elif w > 1:
+                self.comm.send(st.argmax_out, 0)
+        if w > 1 and self.first and n_steps > 0:
+            self.comm.recv(st.token_in, w - 1)       # the last token: where the next call continues from
+        if not collect:
+            return []
+        if w == 1:
+            return [int(t) for t in st.read_tokens(pos0, n_steps)]
+        if self.last:
+            toks = st.read_tokens(pos0, n_steps)
+            buf = st.int_tensor(n_steps)
+            buf.copy_(st.int_tensor(n_steps, toks))
+            self.comm.send(buf, 0)
+            return [int(t) for t in toks]
+        if self.first:
+            buf = st.int_tensor(n_steps)
+            self.comm.recv(buf, w - 1)
+            return [int(t) for t in buf.cpu().tolist()]
+        return []
+
 
 class DevicePtrTensor:
     """Exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
@@ -128,6 +170,29 @@ class HipStage:
             self.block_tokens = 128
             self.block = torch.as_tensor(DevicePtrTensor(engine.stage_hidden_block_ptr(), 128 * engine.hidden_size), device=device)
 
+        tin, aout = engine.stage_io_ptrs()
+        self.token_in = torch.as_tensor(DevicePtrTensor(tin, 1, "<i4"), device=device)
+        self.argmax_out = torch.as_tensor(DevicePtrTensor(aout, 1, "<i4"), device=device)
+        self._torch, self._device = torch, device
+
+    # device-side token feedback (PipelineDecoder.decode_device)
+    def set_token(self, token: int) -> None:
+        self.token_in.fill_(int(token))
+
+    def step_async(self, last: bool) -> None:
+        self.engine.stage_step(2 if last else 0)
+
+    def position(self) -> int:
+        return self.engine.position()
+
+    def read_tokens(self, pos0: int, n: int):
+        return self.engine.stage_read_tokens(pos0, n)
+
+    def int_tensor(self, n: int, values=None):
+        if values is None:
+            return self._torch.zeros(n, dtype=self._torch.int32, device=self._device)
+        return self._torch.tensor([int(v) for v in values], dtype=self._torch.int32, device=self._device)
+
     def run_block(self, tokens, n: int) -> None:
         self.engine.stage_prefill_batch(tokens, n)
 
@@ -136,3 +201,69 @@ class HipStage:
             return int(self.engine.stage_forward(token, want_logits=True, argmax=True))
         self.engine.stage_forward(token)
         return -1
+
+
+class FakeStage:
+    """Protocol test double (CPU tensors, no compute kernels): layer l maps h -> 1.5 h + l + pos / 4, the embedding is keyed by
+    the token, the "arg-max" is a hash of the final vector.  Used by the world_size > 1 `gloo` tests and by
+    `bench.py --fake-stage` (a CPU rehearsal of the launcher and of the hop protocol); never by a measured run."""
+    HID, VOCAB = 16, 97
+
+    def __init__(self, lo: int, hi: int, first: bool, block_tokens: int = 0):
+        import torch
+        self._torch = torch
+        self.lo, self.hi, self.first = lo, hi, first
+        self.hidden = torch.zeros(self.HID, dtype=torch.float32)
+        self.token_buf = torch.zeros(1, dtype=torch.int32)
+        self.token_in = torch.zeros(1, dtype=torch.int32)
+        self.argmax_out = torch.zeros(1, dtype=torch.int32)
+        self.pos = 0
+        self.log = {}
+        self.block_tokens = block_tokens                     # > 0: the stage has a batched prompt path
+        self.block = torch.zeros(max(block_tokens, 1) * self.HID, dtype=torch.float32)
+
+    def _embed(self, dst, token):
+        dst.copy_(self._torch.arange(self.HID, dtype=self._torch.float32) * 0.01 + float(token))
+
+    def run_block(self, tokens, n):
+        rows = self.block[:n * self.HID].view(n, self.HID)
+        for i in range(n):
+            if self.first:
+                self._embed(rows[i], tokens[i])
+            for l in range(self.lo, self.hi):
+                rows[i].mul_(1.5).add_(float(l) + 0.25 * (self.pos + i))
+        self.pos += n
+
+    def run(self, token, last):
+        if self.first:
+            self._embed(self.hidden, token)
+        for l in range(self.lo, self.hi):
+            self.hidden.mul_(1.5).add_(float(l) + 0.25 * self.pos)
+        self.pos += 1
+        if last:
+            return int(self.hidden.abs().sum().item()) % self.VOCAB
+        return -1
+
+    # device-feedback interface (decode_device)
+    def set_token(self, token):
+        self.token_in.fill_(int(token))
+
+    def step_async(self, last):
+        p = self.pos
+        t = self.run(int(self.token_in.item()), last)
+        if last:
+            self.argmax_out.fill_(t)
+            self.log[p] = t
+            if self.first:
+                self.token_in.fill_(t)
+
+    def position(self):
+        return self.pos
+
+    def read_tokens(self, pos0, n):
+        return [self.log[pos0 + i] for i in range(n)]
+
+    def int_tensor(self, n, values=None):
+        if values is None:
+            return self._torch.zeros(n, dtype=self._torch.int32)
+        return self._torch.tensor([int(v) for v in values], dtype=self._torch.int32)

@@ -34,38 +34,9 @@ def test_split_layers():
         pl.split_layers(4, 5)
 
 
-HID, VOCAB = 16, 97
-
-
-class FakeStage:
-    """Deterministic stand-in for a stage context: layer l maps h -> h * 1.5 + l (f32), embedding is token-keyed."""
-
-    def __init__(self, lo, hi, first, block_tokens=0):
-        self.lo, self.hi, self.first = lo, hi, first
-        self.hidden = torch.zeros(HID, dtype=torch.float32)
-        self.token_buf = torch.zeros(1, dtype=torch.int32)
-        self.pos = 0
-        self.block_tokens = block_tokens                     # > 0: the stage has a batched prompt path
-        self.block = torch.zeros(max(block_tokens, 1) * HID, dtype=torch.float32)
-
-    def run_block(self, tokens, n):
-        rows = self.block[:n * HID].view(n, HID)
-        for i in range(n):
-            if self.first:
-                rows[i].copy_(torch.arange(HID, dtype=torch.float32) * 0.01 + float(tokens[i]))
-            for l in range(self.lo, self.hi):
-                rows[i].mul_(1.5).add_(float(l) + 0.25 * (self.pos + i))
-        self.pos += n
-
-    def run(self, token, last):
-        if self.first:
-            self.hidden.copy_(torch.arange(HID, dtype=torch.float32) * 0.01 + float(token))
-        for l in range(self.lo, self.hi):
-            self.hidden.mul_(1.5).add_(float(l) + 0.25 * self.pos)
-        self.pos += 1
-        if last:
-            return int(self.hidden.abs().sum().item()) % VOCAB
-        return -1
+def FakeStage(lo, hi, first, block_tokens=0):
+    """The protocol test double shipped with the package (pipeline.FakeStage): deterministic, CPU tensors, no kernels."""
+    return _pipeline().FakeStage(lo, hi, first, block_tokens)
 
 
 def _reference(n_layers, first_token, n_steps, prompt=()):
@@ -79,7 +50,7 @@ def _reference(n_layers, first_token, n_steps, prompt=()):
     return out
 
 
-def _worker(rank, world, port, n_layers, n_steps, q, prompt=(), block_tokens=0):
+def _worker(rank, world, port, n_layers, n_steps, q, prompt=(), block_tokens=0, device_feedback=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pl = _pipeline()
@@ -87,7 +58,10 @@ def _worker(rank, world, port, n_layers, n_steps, q, prompt=(), block_tokens=0):
     dec = pl.PipelineDecoder(FakeStage(lo, hi, rank == 0, block_tokens), rank, world, pl.TorchComm(dist))
     if prompt:
         dec.prefill(list(prompt))
-    toks = dec.decode(7, n_steps)
+    if device_feedback:     # two calls: the second continues from the token the first left in the first stage
+        toks = dec.decode_device(7, n_steps // 2) + dec.decode_device(None, n_steps - n_steps // 2)
+    else:
+        toks = dec.decode(7, n_steps)
     dist.barrier()
     q.put((rank, toks))
     dist.destroy_process_group()
@@ -134,3 +108,58 @@ def test_pipeline_prefill_blocks_gloo(world, block_tokens):
         assert p.exitcode == 0
     want = _reference(n_layers, 7, n_steps, prompt)
     assert results[0] == want and results[world - 1] == want
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_device_feedback_gloo(world):
+    """decode_device: the arg-max word goes from the last stage's buffer into the first stage's token word by send/recv, no
+    per-token host value; tokens equal the single-stage run; the middle ranks learn nothing."""
+    n_layers, n_steps, prompt = 7, 11, (3, 9, 27)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_layers, n_steps, q, prompt, 0, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = _reference(n_layers, 7, n_steps, prompt)
+    assert results[0] == want and results[world - 1] == want
+    for r in range(1, world - 1):
+        assert results[r] == []
+
+
+def test_single_stage_device_feedback_matches_step_loop():
+    pl = _pipeline()
+
+    class _NoComm:
+        def send(self, *a):
+            raise AssertionError("a single stage sends nothing")
+        recv = send
+    dec = pl.PipelineDecoder(FakeStage(0, 5, True), 0, 1, _NoComm())
+    assert dec.decode_device(7, 9) == _reference(5, 7, 9)
+
+
+def test_bench_self_launches_two_ranks_on_cpu():
+    """`python bench.py --gpus 2` with no launcher around it (the driver's form): the GPU-free parent starts the
+    torch.distributed.run child itself, the two ranks run the hop protocol over gloo with the fake stage, rank 0's single
+    JSON line comes back through the parent, and a failing child makes the parent exit non-zero."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "5", "--warmup", "2", "--prompt", "6", "--fake-stage"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 5 and rec["warmup"] == 2 and rec["unit"] == "tokens/s" and rec["value"] > 0
+    assert rec["repetitions"]["n"] == 3 and "NOT a measurement" in rec["data"]
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "5", "--fake-stage", "--model", "no-such-model", "--prompt", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and not bad.stdout.strip()
