@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 
 #include "../../include/llama_gguf_hip.h"
 
@@ -70,6 +71,7 @@ struct DevWeight {
   const uint8_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};
   uint64_t stack_stride[4] = {0, 0, 0, 0};  // bytes between consecutive experts, per plane
   size_t bytes = 0;         // payload bytes (== algorithmic bytes of one full read)
+  std::vector<bool> filled; // per stacked expert: its payload has been uploaded
   bool present() const { return base != nullptr; }
 };
 

@@ -37,6 +37,8 @@ struct PfScratch {
   float *hidden = nullptr, *q = nullptr, *part = nullptr, *ssq = nullptr;
   size_t part_bytes = 0;
   int* tokens = nullptr;
+  uint32_t* tok_pinned = nullptr;      // pinned host staging of the prompt's token ids, one slot per position
+  hipEvent_t tok_copied = nullptr;     // recorded behind the last copy out of it
   // MoE layers: routing of the block's tokens, tokens grouped by expert, one expert's gathered input, per-slot expert outputs
   int *moe_sel = nullptr, *moe_cnt = nullptr, *moe_base = nullptr, *moe_list = nullptr, *moe_rowmap = nullptr, *moe_tokmap = nullptr;
   float* moe_w = nullptr;
@@ -115,6 +117,7 @@ struct SegSpec {
 };
 
 int fail(lgh_ctx* c, int status, const std::string& msg);
+int engine_shape_check(const lgh_model_desc& d, std::string& why);   // LGH_OK, or the status lgh_create returns and why
 int dev_alloc(lgh_ctx* c, void** p, size_t bytes);
 LayoutInfo layout_for(int src_type);
 bool fused_type(int t);

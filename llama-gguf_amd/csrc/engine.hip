@@ -133,10 +133,12 @@ int upload_matrix(lgh_ctx* c, DevWeight& W, int src_type, uint32_t k, uint32_t n
     for (int p = 0; p < li.nplanes; p++) W.bytes += W.stack_stride[p];  // per expert
     if (t16) W.bytes = per_expert_src;                                  // algorithmic bytes exclude the row padding
     c->stats.weight_bytes += (li.dev_type == LGH_TYPE_F32 ? (uint64_t)n * k * 4 : per_expert_src) * n_stack;
+    W.filled.assign(n_stack, false);
   } else if (W.src_type != src_type || W.k != k || W.n != n || W.n_stack != n_stack) {
     return fail(c, LGH_SHAPE_MISMATCH, "expert tensors of one stack differ in type or shape");
   }
   const uint32_t e0 = slot < 0 ? 0 : (uint32_t)slot;
+  for (uint32_t i = 0; i < n_in_payload; i++) W.filled[e0 + i] = true;   // lgh_finalize refuses a stack with an empty slot
   if (li.dev_type == src_type && li.nplanes == 1 && !t16) {  // native layout: straight copy
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy((void*)(W.plane[0] + (uint64_t)e0 * W.stack_stride[0]), host, nbytes, hipMemcpyHostToDevice));
     return LGH_OK;
@@ -802,7 +804,18 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     return e == hipSuccess ? LGH_OK : fail(c, LGH_OPERATION_FAILED, std::string("batched prefill, ") + what + ": " + hipGetErrorString(e));
   };
   if (c->first) {
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, tokens, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    // The caller's `tokens` may be freed as soon as this returns (lgh_stage_prefill_batch does not synchronise), so the ids
+    // go through a context-owned PINNED buffer, one slot per position; a slot is only rewritten after the copy that last
+    // read it has completed (reset + a second prompt before the first one has run).
+    if (!P.tok_pinned) {
+      HIP_TRY(c, LGH_ALLOCATION_FAILED, hipHostMalloc((void**)&P.tok_pinned, (size_t)d.max_seq_len * 4, hipHostMallocDefault));
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipEventCreateWithFlags(&P.tok_copied, hipEventDisableTiming));
+    } else {
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipEventSynchronize(P.tok_copied));
+    }
+    std::memcpy(P.tok_pinned + pos0, tokens, (size_t)m * 4);
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, P.tok_pinned + pos0, (size_t)m * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipEventRecord(P.tok_copied, st));
     if ((rc = K(embed_batch_launch(c->embd_type, c->embd_raw, P.tokens, P.hidden, H, m, st), "embedding"))) return rc;
   }
   if ((rc = K(pf_row_epi_launch(nullptr, 0, 0, 0, nullptr, P.hidden, H, c->layers[c->l0].attn_norm, P.xh_h, P.ssq, m, st), "attn_norm"))) return rc;
@@ -869,6 +882,31 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// What the engine's kernels are built for, checked BEFORE anything is allocated or uploaded (a Qwen2-7B, 28 / 4 = 7 query
+// heads per kv head, used to fail only in lgh_finalize's warm-up with a generic launch error).
+int engine_shape_check(const lgh_model_desc& d, std::string& why) {
+  if (!d.hidden_size || !d.num_layers || !d.num_heads || !d.num_kv_heads || !d.head_dim || !d.vocab_size || !d.max_seq_len) {
+    why = "a model dimension is zero";
+    return LGH_INVALID_ARGUMENT;
+  }
+  if (d.num_heads % d.num_kv_heads || d.head_dim % 2 || d.hidden_size % 32) {
+    why = "num_heads must be a multiple of num_kv_heads, head_dim even, hidden_size a multiple of 32";
+    return LGH_INVALID_ARGUMENT;
+  }
+  const uint32_t g = d.num_heads / d.num_kv_heads;
+  if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) {
+    why = "decode attention is built for head_dim 64 or 128 and 1, 2, 4 or 8 query heads per kv head; this model has head_dim " +
+          std::to_string(d.head_dim) + " and " + std::to_string(g) + " query heads per kv head";
+    return LGH_UNSUPPORTED;
+  }
+  if (d.num_experts && (d.num_experts_per_token == 0 || d.num_experts_per_token > 2 || d.num_experts > 64)) {
+    why = "MoE layers are built for top-1 / top-2 routing over at most 64 experts; this model routes top-" +
+          std::to_string(d.num_experts_per_token) + " over " + std::to_string(d.num_experts);
+    return LGH_UNSUPPORTED;
+  }
+  return LGH_OK;
+}
+
 extern "C" {
 
 int lgh_device_count(void) {
@@ -881,9 +919,8 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   if (!desc || !out || desc->struct_size != sizeof(lgh_model_desc)) return LGH_INVALID_ARGUMENT;
   *out = nullptr;
   const lgh_model_desc& d = *desc;
-  if (!d.hidden_size || !d.num_layers || !d.num_heads || !d.num_kv_heads || !d.head_dim || !d.vocab_size || !d.max_seq_len)
-    return LGH_INVALID_ARGUMENT;
-  if (d.num_heads % d.num_kv_heads || d.head_dim % 2 || d.hidden_size % 32) return LGH_INVALID_ARGUMENT;
+  std::string why;
+  if (int rc = engine_shape_check(d, why)) return rc;
   int ndev = lgh_device_count();
   if (ndev <= 0 || d.device_id < 0 || d.device_id >= ndev) return LGH_NOT_AVAILABLE;
   lgh_ctx* c = new lgh_ctx();
@@ -1042,6 +1079,16 @@ int lgh_finalize(lgh_ctx* c) {
     if (!L.wq.present() || !L.wk.present() || !L.wv.present() || !L.wo.present()) return fail(c, LGH_INITIALIZATION_FAILED, "missing attention weights of " + p);
     if (L.moe()) {
       if (!L.gate_exps.present() || !L.up_exps.present() || !L.down_exps.present()) return fail(c, LGH_INITIALIZATION_FAILED, "missing expert stacks of " + p);
+      // experts uploaded one at a time (blk.N.ffn_{gate,up,down}.E.weight): every slot of every stack must have arrived,
+      // otherwise the layer would decode from whatever the allocation held
+      const std::pair<const char*, const DevWeight*> stacks[3] = {{"ffn_gate", &L.gate_exps}, {"ffn_up", &L.up_exps}, {"ffn_down", &L.down_exps}};
+      for (const auto& sk : stacks) {
+        std::string missing;
+        for (uint32_t e = 0; e < sk.second->n_stack; e++)
+          if (e >= sk.second->filled.size() || !sk.second->filled[e]) missing += (missing.empty() ? "" : ", ") + std::to_string(e);
+        if (!missing.empty())
+          return fail(c, LGH_INITIALIZATION_FAILED, "missing expert tensors " + p + sk.first + ".{" + missing + "}.weight");
+      }
     } else if (!L.gate.present() || !L.up.present() || !L.down.present()) {
       return fail(c, LGH_INITIALIZATION_FAILED, "missing FFN weights of " + p);
     }
@@ -1125,6 +1172,8 @@ void lgh_destroy(lgh_ctx* c) {
       if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->pf.tok_pinned) (void)hipHostFree(c->pf.tok_pinned);
+  if (c->pf.tok_copied) (void)hipEventDestroy(c->pf.tok_copied);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1342,6 +1391,7 @@ int lgh_synchronize(lgh_ctx* c) {
 int lgh_read_hidden(lgh_ctx* c, float* out) {
   int rc = check_ready(c);
   if (rc) return rc;
+  if (!out) return fail(c, LGH_INVALID_ARGUMENT, "out is NULL");
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(out, c->hidden, (size_t)c->d.hidden_size * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   return LGH_OK;

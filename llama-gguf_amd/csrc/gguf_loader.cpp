@@ -261,6 +261,8 @@ bool known_tensor(const std::string& n) {
 
 }  // namespace
 
+int engine_shape_check(const lgh_model_desc& d, std::string& why);   // engine.hip: what the kernels are built for
+
 extern "C" {
 
 int lgh_gguf_inspect(const char* path, lgh_gguf_info* out, char* err, size_t errlen) {
@@ -296,6 +298,7 @@ int lgh_load_gguf(const char* path, uint32_t max_seq_len, int device, uint32_t f
   d.layer_begin = layer_begin;
   d.layer_end = layer_end;
   lgh_ctx* c = nullptr;
+  if ((rc = engine_shape_check(d, why))) { set_err(err, errlen, why); return rc; }   // names the shape the kernels are not built for
   if ((rc = lgh_create(&d, &c))) { set_err(err, errlen, "lgh_create failed (is a HIP device visible?)"); return rc; }
   for (const TInfo& t : g.tensors) {
     if (!known_tensor(t.name)) continue;   // rope_freqs, tokenizer tables, architectures' extras: not on this path

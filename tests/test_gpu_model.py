@@ -347,3 +347,51 @@ def test_stage_contexts_decode_correctly_in_a_fresh_process():
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_stage_first_capture.py"), *args], check=True,
                              capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
         assert out and out[-1].startswith("rep 0") and out[-1].endswith("max|d|=0.000e+00"), out
+
+
+class _PerExpert:
+    """Hands the experts over one tensor at a time, as the reference's loader renames them
+    (`blk.N.ffn_gate.E.weight`, src/model/loader.rs:1171-1173), optionally leaving some out."""
+
+    def __init__(self, model, drop=()):
+        self._m, self.config, self._drop = model, model.config, set(drop)
+
+    def tensors(self, layers=None):
+        ne_exp = self.config.num_experts
+        for name, t, ne, data in self._m.tensors(layers):
+            if "_exps." not in name:
+                yield name, t, ne, data
+                continue
+            per = data.nbytes // ne_exp
+            for e in range(ne_exp):
+                nm = name.replace("_exps.weight", f".{e}.weight")
+                if nm not in self._drop:
+                    yield nm, t, ne[:2], data[e * per:(e + 1) * per]
+
+
+def test_per_expert_upload_matches_stacks_and_a_missing_expert_fails_finalize(pkg, orc):
+    """Experts uploaded one at a time fill the same device stacks as the 3-D tensors; a model that lacks one expert tensor
+    must fail `lgh_finalize` with InitializationFailed naming it, instead of decoding from uninitialised memory."""
+    cfg = pkg.make_config("test-moe", max_seq_len=16)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    a = pkg.HipGpuInference.from_model(model, 16)
+    b = pkg.HipGpuInference.from_model(_PerExpert(model), 16)
+    for t in (3, 4):
+        a.prefill_token(t)
+        b.prefill_token(t)
+    assert np.array_equal(a.forward(5), b.forward(5))
+    a.close()
+    b.close()
+    with pytest.raises(pkg.BackendError) as ei:
+        pkg.HipGpuInference.from_model(_PerExpert(model, drop={"blk.1.ffn_up.3.weight"}), 16)
+    assert ei.value.variant == "InitializationFailed" and "blk.1.ffn_up.{3}.weight" in str(ei.value)
+
+
+def test_unsupported_attention_shape_is_refused_at_create(pkg):
+    """A shape the kernels are not built for (7 query heads per kv head, Qwen2-7B's 28 / 4) is refused by lgh_create with
+    Unsupported before anything is uploaded, not by a launch error in finalize."""
+    cfg = pkg.make_config("test-dense", max_seq_len=16, num_heads=14, num_kv_heads=2, hidden_size=896)
+    model = pkg.SynthModel(cfg, mix="Q8_0")
+    with pytest.raises(pkg.BackendError) as ei:
+        pkg.HipGpuInference.from_model(model, 16)
+    assert ei.value.variant == "Unsupported"
