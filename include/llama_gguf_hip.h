@@ -312,8 +312,24 @@ typedef struct lgh_gguf_info {
   char architecture[64];             /* general.architecture */
   lgh_model_desc desc;               /* what ModelLoader::parse_config reads from the `{arch}.*` keys; max_seq_len = context_length */
 } lgh_gguf_info;
-/* Parses the header only (no GPU needed).  `err` (optional) receives a message on failure. */
+/* GgufReader::new + read (src/gguf/reader.rs:24-104), header only, no GPU needed.  Accepts every well-formed GGUF v1-v3 as
+ * the reference's reader does; when the `{arch}.*` keys of a model this engine runs are absent, desc.struct_size is 0 (and
+ * `err` says which key is missing) while version / counts / alignment / data_offset are still filled.  Failures carry the
+ * reference's GgufError texts (src/gguf/error.rs:2-19): "Invalid magic number: ...", "Unsupported GGUF version: N"
+ * (status LGH_UNSUPPORTED), "Unexpected end of file". */
 int lgh_gguf_inspect(const char* path, lgh_gguf_info* out, char* err, size_t errlen);
+/* One metadata value by key: GgufData::get_string / get_u32 / get_u64 / get_f32 / get_bool (src/gguf/types.rs:71-104).
+ * type = GGUF value type (0 u8, 1 i8, 2 u16, 3 i16, 4 u32, 5 i32, 6 f32, 7 bool, 8 string, 9 array, 10 u64, 11 i64, 12 f64);
+ * integers (sign-extended) and bools in `u`, floats in `f`, strings in `s` (truncated to 255 bytes), arrays: only `arr_len`. */
+typedef struct lgh_gguf_value {
+  uint32_t type;
+  uint32_t reserved;
+  uint64_t u;
+  double f;
+  uint64_t arr_len;
+  char s[256];
+} lgh_gguf_value;
+int lgh_gguf_get(const char* path, const char* key, lgh_gguf_value* out, char* err, size_t errlen);
 /* create + upload + finalize from a GGUF file.  max_seq_len 0 = the file's context_length; layer_begin/end 0,0 = all. */
 int lgh_load_gguf(const char* path, uint32_t max_seq_len, int device, uint32_t flags, uint32_t layer_begin, uint32_t layer_end,
                   lgh_ctx** out, char* err, size_t errlen);

@@ -118,7 +118,7 @@ int open_map(const char* path, Mapping& m, std::string& why) {
   m.fd = open(path, O_RDONLY);
   if (m.fd < 0) { why = std::string("cannot open ") + path; return LGH_INVALID_ARGUMENT; }
   struct stat st;
-  if (fstat(m.fd, &st) != 0 || st.st_size < 24) { why = "file too small for a GGUF header"; return LGH_INVALID_ARGUMENT; }
+  if (fstat(m.fd, &st) != 0 || st.st_size < 1) { why = "Unexpected end of file"; return LGH_INVALID_ARGUMENT; }   // GgufError::UnexpectedEof
   m.n = (uint64_t)st.st_size;
   void* p = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
   if (p == MAP_FAILED) { why = "mmap failed"; return LGH_ALLOCATION_FAILED; }
@@ -127,12 +127,22 @@ int open_map(const char* path, Mapping& m, std::string& why) {
 }
 
 int parse(const Mapping& m, Parsed& g, std::string& why) {
+  // error vocabulary of the reference's reader (src/gguf/error.rs:2-19; raised at reader.rs:24-47 for the header)
   Cursor c{m.p, m.n};
-  if (c.rd<uint32_t>() != kMagic) { why = "not a GGUF file (bad magic)"; return LGH_INVALID_ARGUMENT; }
+  const uint32_t magic = c.rd<uint32_t>();
+  if (!c.ok) { why = "Unexpected end of file"; return LGH_INVALID_ARGUMENT; }
+  if (magic != kMagic) {
+    char b[80];
+    std::snprintf(b, sizeof(b), "Invalid magic number: expected 0x46554747, got 0x%08X", magic);
+    why = b;
+    return LGH_INVALID_ARGUMENT;
+  }
   g.version = c.rd<uint32_t>();
-  if (g.version < 1 || g.version > 3) { why = "unsupported GGUF version " + std::to_string(g.version); return LGH_UNSUPPORTED; }
+  if (!c.ok) { why = "Unexpected end of file"; return LGH_INVALID_ARGUMENT; }
+  if (g.version < 1 || g.version > 3) { why = "Unsupported GGUF version: " + std::to_string(g.version); return LGH_UNSUPPORTED; }
   const uint64_t n_tensors = c.len(g.version), n_kv = c.len(g.version);   // reader.rs:52-63: u32 counts in v1, u64 after
-  if (!c.ok || n_tensors > kMaxCount || n_kv > kMaxCount) { why = "implausible tensor / metadata counts"; return LGH_INVALID_ARGUMENT; }
+  if (!c.ok) { why = "Unexpected end of file"; return LGH_INVALID_ARGUMENT; }
+  if (n_tensors > kMaxCount || n_kv > kMaxCount) { why = "Invalid data: implausible tensor / metadata counts"; return LGH_INVALID_ARGUMENT; }
   for (uint64_t i = 0; i < n_kv; i++) {
     std::string key = c.str(g.version);
     Value v;
@@ -152,7 +162,8 @@ int parse(const Mapping& m, Parsed& g, std::string& why) {
   auto a = g.kv.find("general.alignment");   // reader.rs:84-92
   if (a != g.kv.end() && (a->second.type == U32 || a->second.type == U64) && a->second.u >= 1 && a->second.u <= (1u << 20)) g.alignment = (uint32_t)a->second.u;
   g.data_offset = (c.pos + g.alignment - 1) / g.alignment * g.alignment;
-  if (g.data_offset > m.n) { why = "data section beyond the end of the file"; return LGH_INVALID_ARGUMENT; }
+  // (a file without tensors may end before its aligned data offset: reader.rs:84-96 only computes the offset)
+  if (g.data_offset > m.n && !g.tensors.empty()) { why = "Invalid data: data section beyond the end of the file"; return LGH_INVALID_ARGUMENT; }
   return LGH_OK;
 }
 
@@ -196,7 +207,7 @@ int describe(const Parsed& g, lgh_gguf_info& info, std::string& why) {
   info.alignment = g.alignment;
   info.data_offset = g.data_offset;
   auto ai = g.kv.find("general.architecture");
-  if (ai == g.kv.end() || ai->second.type != STR) { why = "general.architecture missing"; return LGH_INVALID_ARGUMENT; }
+  if (ai == g.kv.end() || ai->second.type != STR) { why = "general.architecture missing"; return LGH_INVALID_ARGUMENT; }   // (header fields above stay filled)
   const std::string arch = ai->second.s;
   std::snprintf(info.architecture, sizeof(info.architecture), "%s", arch.c_str());
   lgh_model_desc& d = info.desc;
@@ -272,10 +283,38 @@ int lgh_gguf_inspect(const char* path, lgh_gguf_info* out, char* err, size_t err
   std::string why;
   int rc = open_map(path, m, why);
   if (!rc) rc = parse(m, g, why);
-  if (!rc) rc = describe(g, *out, why);
-  if (!rc) out->file_bytes = m.n;
-  if (rc) set_err(err, errlen, why);
-  return rc;
+  if (rc) { set_err(err, errlen, why); return rc; }
+  // A well-formed GGUF that is not a model of this engine's families (the reference's reader accepts any metadata,
+  // tests/gguf_reader_test.rs:4-44) still inspects fine: header fields filled, desc.struct_size == 0 says "no model config"
+  // (ModelLoader::parse_config would be the one to complain, loader.rs:62-77 — here lgh_load_gguf).
+  std::string model_why;
+  if (describe(g, *out, model_why) != LGH_OK) {
+    out->desc = lgh_model_desc{};
+    set_err(err, errlen, model_why);
+  }
+  out->file_bytes = m.n;
+  return LGH_OK;
+}
+
+/* GgufData::get_string / get_u32 / get_u64 / get_f32 / get_bool (src/gguf/types.rs:71-104): one metadata value by key. */
+int lgh_gguf_get(const char* path, const char* key, lgh_gguf_value* out, char* err, size_t errlen) {
+  if (!path || !key || !out) return LGH_INVALID_ARGUMENT;
+  Mapping m;
+  Parsed g;
+  std::string why;
+  int rc = open_map(path, m, why);
+  if (!rc) rc = parse(m, g, why);
+  if (rc) { set_err(err, errlen, why); return rc; }
+  auto it = g.kv.find(key);
+  if (it == g.kv.end()) { set_err(err, errlen, std::string("no metadata key ") + key); return LGH_INVALID_ARGUMENT; }
+  std::memset(out, 0, sizeof(*out));
+  const Value& v = it->second;
+  out->type = v.type;
+  out->u = v.u;
+  out->f = v.f;
+  out->arr_len = v.arr_len;
+  std::snprintf(out->s, sizeof(out->s), "%s", v.s.c_str());
+  return LGH_OK;
 }
 
 int lgh_load_gguf(const char* path, uint32_t max_seq_len, int device, uint32_t flags, uint32_t layer_begin, uint32_t layer_end,
@@ -288,7 +327,7 @@ int lgh_load_gguf(const char* path, uint32_t max_seq_len, int device, uint32_t f
   std::string why;
   int rc = open_map(path, m, why);
   if (!rc) rc = parse(m, g, why);
-  if (!rc) rc = describe(g, info, why);
+  if (!rc) rc = describe(g, info, why);   // ModelLoader::parse_config's required keys (loader.rs:62-77)
   if (!rc && !arch_supported(info.architecture)) { rc = LGH_UNSUPPORTED; why = std::string("architecture '") + info.architecture + "' is not on this engine's path"; }
   if (rc) { set_err(err, errlen, why); return rc; }
   lgh_model_desc d = info.desc;

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
     "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
-    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens",
+    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
@@ -72,6 +72,11 @@ class ModelDesc(C.Structure):
 class GgufInfo(C.Structure):
     _fields_ = [("version", C.c_uint32), ("alignment", C.c_uint32), ("n_tensors", C.c_uint64), ("n_kv", C.c_uint64),
                 ("data_offset", C.c_uint64), ("file_bytes", C.c_uint64), ("architecture", C.c_char * 64), ("desc", ModelDesc)]
+
+
+class GgufValue(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("reserved", C.c_uint32), ("u", C.c_uint64), ("f", C.c_double), ("arr_len", C.c_uint64),
+                ("s", C.c_char * 256)]
 
 
 class Stats(C.Structure):
@@ -136,6 +141,7 @@ def load_library() -> C.CDLL:
         "lgh_load_gguf": (C.c_int, [C.c_char_p, u32, C.c_int, u32, u32, u32, C.POINTER(vp), C.c_char_p, sz]),
         "lgh_stage_io_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]), "lgh_stage_step": (C.c_int, [vp, C.c_int]),
         "lgh_stage_read_tokens": (C.c_int, [vp, sz, sz, vp]),
+        "lgh_gguf_get": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GgufValue), C.c_char_p, sz]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -622,4 +628,32 @@ def gguf_inspect(path: str) -> dict:
         raise BackendError(rc, "lgh_gguf_inspect: " + err.value.decode(errors="replace"))
     return {"version": info.version, "alignment": info.alignment, "n_tensors": info.n_tensors, "n_kv": info.n_kv,
             "data_offset": info.data_offset, "file_bytes": info.file_bytes, "architecture": info.architecture.decode(),
+            "has_model_config": info.desc.struct_size != 0, "note": err.value.decode(errors="replace"),
             "desc": {n: getattr(info.desc, n) for n, _ in ModelDesc._fields_}}
+
+
+GGUF_VALUE_TYPES = ("u8", "i8", "u16", "i16", "u32", "i32", "f32", "bool", "string", "array", "u64", "i64", "f64")
+
+
+def gguf_get(path: str, key: str):
+    """One metadata value: (type name, python value) — GgufData::get_* (src/gguf/types.rs:71-104); None when absent."""
+    v = GgufValue()
+    err = C.create_string_buffer(512)
+    rc = load_library().lgh_gguf_get(path.encode(), key.encode(), C.byref(v), err, len(err))
+    if rc:
+        msg = err.value.decode(errors="replace")
+        if msg.startswith("no metadata key"):
+            return None
+        raise BackendError(rc, "lgh_gguf_get: " + msg)
+    t = GGUF_VALUE_TYPES[v.type]
+    if t in ("f32", "f64"):
+        return t, float(v.f)
+    if t == "string":
+        return t, v.s.decode(errors="replace")
+    if t == "array":
+        return t, int(v.arr_len)
+    if t == "bool":
+        return t, bool(v.u)
+    if t in ("i8", "i16", "i32", "i64"):
+        return t, int(C.c_int64(v.u).value)
+    return t, int(v.u)

@@ -207,6 +207,21 @@ void orc_axpy_f32(float alpha, const float* x, float* y, size_t n) {  // simd.rs
   for (size_t i = done; i < n; i++) y[i] += alpha * x[i];
 }
 
+float orc_sum_f32(const float* a, size_t n) {  // simd.rs:449-487: AVX2 whenever the host has it (8 lanes + hsum_avx2, scalar tail), else sequential
+  if (resolve_isa() == ORC_ISA_SCALAR) {
+    float s = 0.0f;
+    for (size_t i = 0; i < n; i++) s += a[i];
+    return s;
+  }
+  float lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const size_t chunks = n / 8;
+  for (size_t c = 0; c < chunks; c++)
+    for (int l = 0; l < 8; l++) lanes[l] += a[c * 8 + l];
+  float r = hsum8(lanes);
+  for (size_t i = chunks * 8; i < n; i++) r += a[i];
+  return r;
+}
+
 float orc_max_f32(const float* x, size_t n) {  // simd.rs:511-563 (order-independent for non-NaN)
   float m = -std::numeric_limits<float>::infinity();
   for (size_t i = 0; i < n; i++) m = x[i] > m ? x[i] : m;

@@ -81,6 +81,7 @@ void orc_attention(const float* q, const float* k, const float* v, float* out, s
 void orc_silu(const float* x, float* out, size_t n);
 void orc_silu_mul_inplace(float* gate, const float* up, size_t n);
 float orc_max_f32(const float* x, size_t n);
+float orc_sum_f32(const float* a, size_t n);   /* simd.rs:449-487 */
 void orc_axpy_f32(float alpha, const float* x, float* y, size_t n);
 
 /* bench arg-max (main.rs:1815-1821): last maximal index */

@@ -70,7 +70,7 @@ def lib() -> C.CDLL:
         "orc_gelu": (None, [vp, vp, sz]), "orc_softmax_rows": (None, [vp, vp, sz, sz]),
         "orc_matmul": (None, [vp, vp, vp, sz, sz, sz]), "orc_matvec": (None, [vp, vp, vp, sz, sz]),
         "orc_attention": (None, [vp, vp, vp, vp, sz, sz, sz, sz, sz, C.c_float]),
-        "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]),
+        "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]), "orc_sum_f32": (C.c_float, [vp, sz]),
         "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
         "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),

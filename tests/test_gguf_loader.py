@@ -92,3 +92,129 @@ def test_load_gguf_rejects_other_architectures_and_bad_tensors(gpu, pkg, tmp_pat
     write_gguf(p2, cfg, [t for t in model.tensors() if "blk.1.ffn_down" not in t[0]])
     with pytest.raises(pkg.BackendError):
         pkg.HipGpuInference.from_gguf(p2, 64)     # finalize: a tensor the stage needs is absent
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own reader fixtures (tests/gguf_reader_test.rs:4-160), restated byte for byte and pushed through
+# lgh_gguf_inspect / lgh_gguf_get: these pin the loader's header parser to the reference, not to tools/write_gguf.py.
+# ---------------------------------------------------------------------------------------------------------------
+GGUF_MAGIC = 0x46554747          # src/gguf/constants.rs:4
+
+
+def _minimal_v3():               # gguf_reader_test.rs:4-24
+    key, val = b"general.architecture", b"llama"
+    return (struct.pack("<IIQQ", GGUF_MAGIC, 3, 0, 1) + struct.pack("<Q", len(key)) + key + struct.pack("<I", 8)
+            + struct.pack("<Q", len(val)) + val)
+
+
+def _minimal_v1():               # gguf_reader_test.rs:26-44: u32 counts and u32 string lengths
+    key = b"test.key"
+    return struct.pack("<IIII", GGUF_MAGIC, 1, 0, 1) + struct.pack("<I", len(key)) + key + struct.pack("<II", 4, 42)
+
+
+def _put(tmp_path, name, blob):
+    p = str(tmp_path / name)
+    open(p, "wb").write(blob)
+    return p
+
+
+def test_reference_fixture_minimal_v3(pkg, tmp_path):
+    """test_read_minimal_gguf (gguf_reader_test.rs:46-56) + test_data_offset_alignment (:153-160)."""
+    p = _put(tmp_path, "v3.gguf", _minimal_v3())
+    info = pkg.hip_backend.gguf_inspect(p)
+    assert info["version"] == 3 and info["n_tensors"] == 0 and info["n_kv"] == 1
+    assert pkg.hip_backend.gguf_get(p, "general.architecture") == ("string", "llama")
+    assert info["architecture"] == "llama"
+    assert info["data_offset"] % 32 == 0 and info["alignment"] == 32
+    assert not info["has_model_config"] and "embedding_length" in info["note"]   # a valid GGUF, but not a model: lgh_load_gguf refuses it
+    assert pkg.hip_backend.gguf_get(p, "no.such.key") is None
+
+
+def test_reference_fixture_v1_u32_counts(pkg, tmp_path):
+    """test_read_gguf_v1 (gguf_reader_test.rs:58-68)."""
+    p = _put(tmp_path, "v1.gguf", _minimal_v1())
+    info = pkg.hip_backend.gguf_inspect(p)
+    assert info["version"] == 1 and info["n_tensors"] == 0 and info["n_kv"] == 1
+    assert pkg.hip_backend.gguf_get(p, "test.key") == ("u32", 42)
+    assert not info["has_model_config"]
+
+
+def test_reference_fixture_invalid_magic_version_eof(pkg, tmp_path):
+    """test_invalid_magic (:70-76), test_unsupported_version (:78-87), test_unexpected_eof (:142-150): the reference's
+    GgufError variants, carried as status + the reference's message text (src/gguf/error.rs:3-14)."""
+    hb = pkg.hip_backend
+    with pytest.raises(pkg.BackendError) as ei:
+        hb.gguf_inspect(_put(tmp_path, "magic.gguf", bytes([0, 0, 0, 0, 3, 0, 0, 0])))
+    assert ei.value.variant == "InvalidArgument" and "Invalid magic number: expected 0x46554747, got 0x00000000" in str(ei.value)
+    with pytest.raises(pkg.BackendError) as ei:
+        hb.gguf_inspect(_put(tmp_path, "ver.gguf", struct.pack("<II", GGUF_MAGIC, 99)))
+    assert ei.value.variant == "Unsupported" and "Unsupported GGUF version: 99" in str(ei.value)
+    with pytest.raises(pkg.BackendError) as ei:
+        hb.gguf_inspect(_put(tmp_path, "eof.gguf", struct.pack("<I", GGUF_MAGIC)))
+    assert ei.value.variant == "InvalidArgument" and "Unexpected end of file" in str(ei.value)
+
+
+def test_reference_fixture_every_metadata_type(pkg, tmp_path):
+    """test_multiple_metadata_types (gguf_reader_test.rs:89-140): u8, i32, f32, bool, u64 — plus the remaining scalar types,
+    a string array and an array of arrays, which the reader also has to step over (reader.rs:106-190)."""
+    def kv(key, vtype, payload):
+        return struct.pack("<Q", len(key)) + key + struct.pack("<I", vtype) + payload
+    body = (kv(b"test.u8", 0, bytes([255])) + kv(b"test.i32", 5, struct.pack("<i", -42)) + kv(b"test.f32", 6, struct.pack("<f", 2.5))
+            + kv(b"test.bool", 7, bytes([1])) + kv(b"test.u64", 10, struct.pack("<Q", 0xFFFFFFFFFFFFFFFF)))
+    p = _put(tmp_path, "types5.gguf", struct.pack("<IIQQ", GGUF_MAGIC, 3, 0, 5) + body)
+    hb = pkg.hip_backend
+    info = hb.gguf_inspect(p)
+    assert info["n_kv"] == 5
+    assert hb.gguf_get(p, "test.u64") == ("u64", 0xFFFFFFFFFFFFFFFF)
+    assert hb.gguf_get(p, "test.f32") == ("f32", 2.5)
+    assert hb.gguf_get(p, "test.u8") == ("u8", 255) and hb.gguf_get(p, "test.i32") == ("i32", -42) and hb.gguf_get(p, "test.bool") == ("bool", True)
+    more = (kv(b"t.i8", 1, struct.pack("<b", -7)) + kv(b"t.u16", 2, struct.pack("<H", 65535)) + kv(b"t.i16", 3, struct.pack("<h", -300))
+            + kv(b"t.i64", 11, struct.pack("<q", -(1 << 40))) + kv(b"t.f64", 12, struct.pack("<d", 1.25))
+            + kv(b"t.strs", 9, struct.pack("<IQ", 8, 2) + struct.pack("<Q", 2) + b"ab" + struct.pack("<Q", 0))
+            + kv(b"t.nested", 9, struct.pack("<IQ", 9, 2) + struct.pack("<IQ", 4, 2) + struct.pack("<II", 1, 2) + struct.pack("<IQ", 0, 1) + b"\x09")
+            + kv(b"general.alignment", 4, struct.pack("<I", 64)))
+    p2 = _put(tmp_path, "types_more.gguf", struct.pack("<IIQQ", GGUF_MAGIC, 3, 0, 8) + more)
+    info = hb.gguf_inspect(p2)
+    assert info["n_kv"] == 8 and info["alignment"] == 64 and info["data_offset"] % 64 == 0      # reader.rs:84-96
+    assert hb.gguf_get(p2, "t.i8") == ("i8", -7) and hb.gguf_get(p2, "t.u16") == ("u16", 65535) and hb.gguf_get(p2, "t.i16") == ("i16", -300)
+    assert hb.gguf_get(p2, "t.i64") == ("i64", -(1 << 40)) and hb.gguf_get(p2, "t.f64") == ("f64", 1.25)
+    assert hb.gguf_get(p2, "t.strs") == ("array", 2) and hb.gguf_get(p2, "t.nested") == ("array", 2)
+    with pytest.raises(pkg.BackendError) as ei:   # an unknown value type: GgufError::InvalidMetadataType
+        hb.gguf_inspect(_put(tmp_path, "badtype.gguf", struct.pack("<IIQQ", GGUF_MAGIC, 3, 0, 1) + kv(b"x", 77, b"\0\0\0\0")))
+    assert ei.value.variant == "InvalidArgument"
+
+
+@pytest.mark.gpu
+def test_load_gguf_refuses_a_gguf_without_model_keys(gpu, pkg, tmp_path):
+    with pytest.raises(pkg.BackendError) as ei:
+        pkg.HipGpuInference.from_gguf(_put(tmp_path, "v3.gguf", _minimal_v3()), 64)
+    assert ei.value.variant == "InvalidArgument" and "embedding_length" in str(ei.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mix", [("test-dense", "Q4_K_M"), ("test-moe", "Q5_K_M"), ("test-dense-d128", "Q8_0")])
+def test_gguf_loaded_model_matches_the_oracle(gpu, pkg, orc, tmp_path, name, mix):
+    """The loader against the ORACLE (not against the engine's own upload path): a model read from a GGUF file gives the CPU
+    oracle's logits and greedy tokens."""
+    cfg, model, path, _ = _write(pkg, tmp_path, name, mix)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    eng = pkg.HipGpuInference.from_gguf(path, 64)
+    try:
+        toks = [3, 77, 500, 9]
+        for t in toks[:-1]:
+            eng.prefill_token(t)
+        got, want = eng.forward(toks[-1]), ref.forward(toks)
+        for _ in range(6):
+            err = float(np.abs(got - want).max())
+            assert err <= 2e-3 * float(np.abs(want).max()) + 2e-3
+            srt = np.sort(want)
+            tok = orc.argmax_last(want)
+            if float(srt[-1] - srt[-2]) > 4 * err:
+                assert orc.argmax_last(got) == tok
+            got, want = eng.forward(tok), ref.forward([tok])
+    finally:
+        ref.close()
+        eng.close()

@@ -132,6 +132,26 @@ def test_simd_kats(orc):
     assert np.allclose(orc.silu([0.0, 1.0, -1.0]), [0.0, 0.7310586, -0.26894143], atol=1e-6)
 
 
+def test_simd_kats_sum_scale_silu_mul_axpy(orc):
+    """The remaining known-answer tests of src/backend/cpu/simd.rs:1184-1263 (test_sum, test_scale, test_silu_mul_inplace,
+    test_axpy), on every ISA path the reference dispatches to."""
+    L = orc.lib()
+    for isa in (orc.ISA_SCALAR, orc.ISA_AVX2, orc.ISA_AVX512):
+        orc.set_isa(isa)
+        a = np.arange(1, 11, dtype=np.float32)
+        assert abs(L.orc_sum_f32(a.ctypes.data, 10) - 55.0) < 1e-6                       # simd.rs:1184-1189
+        a8 = np.arange(1, 9, dtype=np.float32)
+        assert np.all(np.abs(orc.scale(a8, 2.0) - a8 * 2.0) < 1e-6)                      # simd.rs:1221-1231
+        gate = np.array([1.0, -1.0, 2.0, 0.0, 0.5, -0.5, 3.0, -2.0], np.float32)         # simd.rs:1233-1252
+        up = np.array([2.0, 3.0, 1.0, 5.0, 4.0, 2.0, 0.5, 1.0], np.float32)
+        want = np.array([x / (1.0 + np.exp(np.float32(-x))) * u for x, u in zip(gate, up)], np.float32)
+        assert np.all(np.abs(orc.silu_mul(gate, up) - want) < 1e-5)
+        y = np.arange(10, 90, 10, dtype=np.float32)                                       # simd.rs:1254-1273
+        L.orc_axpy_f32(2.0, a8.ctypes.data, y.ctypes.data, 8)
+        assert np.all(np.abs(y - np.array([12, 24, 36, 48, 60, 72, 84, 96], np.float32)) < 1e-6)
+    orc.set_isa(orc.ISA_AUTO)
+
+
 def test_dot_f32_isa_variants_agree_to_rounding(orc):
     rng = np.random.default_rng(7)
     a, b = rng.standard_normal(4099).astype(np.float32), rng.standard_normal(4099).astype(np.float32)
