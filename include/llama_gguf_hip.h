@@ -88,6 +88,7 @@ enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
   LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
   LGH_FLAG_EXACT_PREFILL = 1u << 2,  /* lgh_prefill_batch feeds the tokens one by one (f32 throughout) instead of the batched f16 GEMM path */
+  LGH_FLAG_NO_PERSISTENT = 1u << 3,  /* decode as one launch per op (hipGraph of ~6 kernels per layer) instead of the persistent token kernel */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
   LGH_FLAG_ATTN_DIRECT_SHIFT = 16    /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
                                         per kv head, no split + combine pair); 0 = the tuned default, 255 = never */
@@ -98,7 +99,9 @@ typedef struct lgh_ctx lgh_ctx;
 /* kernel classes reported by lgh_get_stats (profiling mode) */
 enum {
   LGH_K_EMBED = 0, LGH_K_QKV = 1, LGH_K_ATTN = 2, LGH_K_ATTN_COMBINE = 3, LGH_K_WO = 4, LGH_K_GATEUP = 5,
-  LGH_K_DOWN = 6, LGH_K_ROUTER = 7, LGH_K_OUTPUT = 8, LGH_K_ARGMAX = 9, LGH_K_MISC = 10, LGH_K_COUNT = 16
+  LGH_K_DOWN = 6, LGH_K_ROUTER = 7, LGH_K_OUTPUT = 8, LGH_K_ARGMAX = 9, LGH_K_MISC = 10,
+  LGH_K_TOKEN = 11,   /* the persistent token kernel: every mat-vec and attention op of a decode step in one launch */
+  LGH_K_COUNT = 16
 };
 
 /* kernel SYMBOLS reported by lgh_get_stats (profiling mode): what `rocprofv3 --kernel-trace --stats` groups by.
@@ -124,7 +127,8 @@ enum {
   LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
   LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u> / <6u> : Q5_K (and Q5_K + Q6_K) */
   LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u> / <16u> : Q8_0 / Q4_0 */
-  LGH_SYM_COUNT = 20
+  LGH_SYM_PTOK = 20,       /* lgh::ptok_kernel<MASK, D, G> : the persistent token kernel (decode_persistent.hip) */
+  LGH_SYM_COUNT = 24
 };
 
 typedef struct lgh_stats {

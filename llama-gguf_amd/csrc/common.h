@@ -168,6 +168,8 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st);   // streaming-read probe
+// launch-uniform geometry of one int8-MFMA op, packed as the kernel takes it; returns the format mask (0 = not launchable)
+uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out);
 hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h);
 hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st);
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);

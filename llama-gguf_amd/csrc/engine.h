@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ptok.h"
 
 namespace lgh {
 
@@ -47,6 +48,20 @@ struct PfScratch {
 
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
+// The persistent token kernel's program for one graph mode (decode_persistent.hip): built once at finalize.
+struct PtProg {
+  bool built = false, usable = false;
+  std::vector<PtHostOp> ops;
+  uint8_t* dev = nullptr;        // device image: PtOp[n], MvLaunch[n_mv], PtAttn[n_attn]
+  unsigned* sync = nullptr;      // epoch, error flag, hand-off counters (never reset: they only grow)
+  PtProgram P{};
+  uint32_t mask = 0;
+  size_t lds = 0;
+  uint64_t weight_bytes = 0;     // algorithmic bytes of the program's matrices + vectors (KV rows are added per position)
+  const float* first_nw = nullptr;   // norm weights the program's first op expects its input XQ image multiplied with
+  std::string why;               // why the program cannot be used (diagnostics)
+};
+
 }  // namespace lgh
 
 struct lgh_ctx {
@@ -87,6 +102,9 @@ struct lgh_ctx {
   std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
   unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
   lgh::PfScratch pf;
+  lgh::PtProg pt[lgh::MODE_COUNT];             // persistent token kernel, per graph mode
+  float* pt_part = nullptr;                    // attention split partials of the persistent kernel
+  uint32_t pt_s_max = 0, pt_rows_per_split = 64;
   float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 

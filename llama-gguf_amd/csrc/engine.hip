@@ -581,8 +581,225 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   return LGH_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The persistent token kernel's program (decode_persistent.hip): every mat-vec and attention op of a decode step of this
+// context, in order, with the hand-off counters between them.  Built once per graph mode at finalize (never during a
+// capture); the launch-per-op path stays behind it for everything the kernel is not built for (MoE layers, formats
+// outside the tile layouts, NeoX RoPE, odd head shapes) and behind LGH_FLAG_NO_PERSISTENT.
+// ------------------------------------------------------------------------------------------------
+static int ilog2(uint32_t v) { int s = 0; while ((1u << s) < v) s++; return s; }
+
+static int pt_build(lgh_ctx* c, int mode) {
+  PtProg& R = c->pt[mode];
+  if (R.built) return LGH_OK;
+  R.built = true;
+  R.usable = false;
+  const lgh_model_desc& d = c->d;
+  const uint32_t H = d.hidden_size, D = d.head_dim, NH = d.num_heads, NKV = d.num_kv_heads, G = NH / NKV;
+  auto no = [&](const std::string& why) { R.why = why; return LGH_OK; };
+  if (d.flags & (LGH_FLAG_NO_PERSISTENT | LGH_FLAG_CHAIN_FFN)) return no("disabled by flag");
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < kNumCU) return no("device has fewer than 256 CUs");
+  if (H % 256 || (NH * D) % 256 || d.use_neox_rope || c->l0 >= c->l1) return no("shape");
+  const bool head = c->last && mode != MODE_PREFILL;
+  if (head && !mfma_type(c->output.type)) return no("output projection is not in a tile layout");
+  for (uint32_t li = c->l0; li < c->l1; li++) {
+    const LayerW& Lw = c->layers[li];
+    if (Lw.moe()) return no("MoE layer");
+    for (const DevWeight* W : {&Lw.wq, &Lw.wk, &Lw.wv, &Lw.wo, &Lw.gate, &Lw.up, &Lw.down})
+      if (!mfma_type(W->type) || W->n % 16) return no("a matrix is not in a tile layout");
+    if (Lw.gate.type != Lw.up.type || d.intermediate_size % 256) return no("FFN shape");
+  }
+  // ---- ops
+  std::vector<PtHostOp>& ops = R.ops;
+  ops.clear();
+  uint32_t ncnt = 0;
+  uint64_t bytes = 0;
+  bool bad = false;
+  auto add_mv = [&](const SegSpec* sp, int nseg, const float* norm_w, uint32_t k, uint32_t in_kind, uint32_t in_cnt) -> PtHostOp* {
+    PtHostOp h{};
+    uint32_t wg = 0, threads = 0;
+    uint64_t alg = 0;
+    if (build_mv_group(c, sp, nseg, norm_w, k, true, h.mv, wg, threads, alg)) { bad = true; return nullptr; }
+    MvChainOp g;
+    size_t lds = 0;
+    if (!mvq_pack(h.mv, wg, threads, &g, &lds) || threads != (uint32_t)kPtWaves * 64 || wg > (uint32_t)kNumCU || h.mv.seg[0].units > 64) { bad = true; return nullptr; }
+    for (int s = 0; s < nseg; s++)
+      for (int p = 0; p < h.mv.seg[s].npass; p++)
+        if (h.mv.seg[s].pass[p].sel) { bad = true; return nullptr; }
+    h.op.kind = PT_MV;
+    h.op.n_wg = wg;
+    h.op.wbpack = g.wbpack; h.op.geom = g.geom; h.op.geom2 = g.geom2; h.op.red_floats = g.red_floats; h.op.lds_red_off = g.lds_red_off;
+    h.op.in_kind = in_kind;
+    h.op.in_cnt = in_cnt;
+    for (int s = 0; s < 3; s++) { h.op.out_cnt[s] = kPtNone; h.op.out_shift[s] = 0; }
+    h.op.next_mv = kPtNone;
+    h.op.attn = kPtNone;
+    h.threads = threads;
+    h.alg_bytes = alg;
+    bytes += alg;
+    ops.push_back(h);
+    return &ops.back();
+  };
+  for (auto& q : c->xqs) q.fresh = false;
+  XqBuf* qh = xq_get(c, c->hidden, H);
+  XqBuf* qa = xq_get(c, c->attn_out, NH * D);
+  if (!qh || !qa) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
+  R.first_nw = c->layers[c->l0].attn_norm;
+  qh->fresh = true;            // left by the embedding kernel (first stage) or converted in front of the launch (other stages)
+  qh->tag = R.first_nw;
+  uint32_t in_kind = PT_IN_READY, in_cnt = 0;
+  const float scale = 1.0f / std::sqrt((float)D);   // layers.rs:374
+  for (uint32_t li = c->l0; li < c->l1 && !bad; li++) {
+    LayerW& Lw = c->layers[li];
+    const float* next_nw = nullptr;
+    bool next_mfma = false;
+    if (li + 1 < c->l1) { next_nw = c->layers[li + 1].attn_norm; next_mfma = true; }
+    else if (head) { next_nw = c->output_norm; next_mfma = true; }
+    // QKV (+ RoPE + cache write): signal groups of head_dim rows — q heads, k heads, v heads
+    SegSpec sq[3];
+    sq[0].W[0] = &Lw.wq; sq[0].x[0] = c->hidden; sq[0].epi = EPI_ROPE_Q; sq[0].out = c->q; sq[0].bias = Lw.bq;
+    sq[1].W[0] = &Lw.wk; sq[1].x[0] = c->hidden; sq[1].epi = EPI_ROPE_K; sq[1].out = Lw.kcache; sq[1].bias = Lw.bk;
+    sq[2].W[0] = &Lw.wv; sq[2].x[0] = c->hidden; sq[2].epi = EPI_V_CACHE; sq[2].out = Lw.vcache; sq[2].bias = Lw.bv;
+    PtHostOp* o = add_mv(sq, 3, Lw.attn_norm, H, in_kind, in_cnt);
+    if (!o) break;
+    const uint32_t qkv_cnt = ncnt;
+    o->op.out_cnt[0] = qkv_cnt; o->op.out_cnt[1] = qkv_cnt + NH; o->op.out_cnt[2] = qkv_cnt + NH + NKV;
+    o->op.out_shift[0] = o->op.out_shift[1] = o->op.out_shift[2] = (uint32_t)ilog2(D);
+    ncnt += NH + 2 * NKV;
+    // attention
+    PtHostOp a{};
+    a.op.kind = PT_ATTN;
+    a.op.next_mv = kPtNone;
+    a.op.attn = 0;   // patched below (index into the PtAttn array)
+    a.attn.q = c->q; a.attn.kc = Lw.kcache; a.attn.vc = Lw.vcache; a.attn.part = c->pt_part; a.attn.pos = c->state + ST_POS;
+    a.attn.scale = scale; a.attn.n_heads = NH; a.attn.n_kv = NKV; a.attn.max_seq = d.max_seq_len;
+    a.attn.in_cnt = qkv_cnt; a.attn.out_cnt = ncnt; a.attn.s_max = c->pt_s_max; a.attn.rows_per_split = c->pt_rows_per_split;
+    const uint32_t attn_cnt = ncnt;
+    ncnt += NKV;
+    ops.push_back(a);
+    const size_t attn_at = ops.size() - 1;
+    // wo (+ residual): its input is merged from the attention partials by the consumer waves
+    qa->fresh = true; qa->tag = nullptr;
+    SegSpec so;
+    so.W[0] = &Lw.wo; so.x[0] = c->attn_out; so.epi = EPI_RESID; so.out = c->hidden; so.resid = c->hidden; so.bias = Lw.bo;
+    so.xq_next = 2; so.xq_next_nw = Lw.ffn_norm;
+    o = add_mv(&so, 1, nullptr, Lw.wo.k, PT_IN_ATTN, attn_cnt);
+    if (!o) break;
+    o->op.attn = (uint32_t)attn_at;   // (ops index for now; translated to the PtAttn index when the image is laid out)
+    o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
+    uint32_t prev_cnt = ncnt;
+    ncnt += H / 256;
+    // gate | up (+ SwiGLU)
+    SegSpec sg;
+    sg.npass = 2; sg.W[0] = &Lw.gate; sg.W[1] = &Lw.up; sg.x[0] = sg.x[1] = c->hidden; sg.epi = EPI_SWIGLU; sg.out = c->act; sg.xq_next = 1;
+    o = add_mv(&sg, 1, Lw.ffn_norm, H, PT_IN_XQ, prev_cnt);
+    if (!o) break;
+    o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
+    prev_cnt = ncnt;
+    ncnt += d.intermediate_size / 256;
+    // down (+ residual)
+    SegSpec sd;
+    sd.W[0] = &Lw.down; sd.x[0] = c->act; sd.epi = EPI_RESID; sd.out = c->hidden; sd.resid = c->hidden;
+    sd.xq_next = next_mfma ? 2 : 0; sd.xq_next_nw = next_nw;
+    o = add_mv(&sd, 1, nullptr, Lw.down.k, PT_IN_XQ, prev_cnt);
+    if (!o) break;
+    if (next_mfma) {
+      o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
+      in_kind = PT_IN_XQ; in_cnt = ncnt;
+      ncnt += H / 256;
+    }
+  }
+  if (!bad && head) {
+    SegSpec sp;
+    sp.W[0] = &c->output; sp.x[0] = c->hidden; sp.epi = EPI_STORE; sp.out = c->logits;
+    if (!add_mv(&sp, 1, c->output_norm, H, in_kind, in_cnt)) bad = true;
+  }
+  for (auto& q : c->xqs) q.fresh = false;
+  if (bad) { ops.clear(); return no("an op's geometry does not fit the persistent kernel"); }
+  R.mask = ptok_mask(ops.data(), ops.size());
+  if (!R.mask || !ptok_supported(R.mask, D, G)) { ops.clear(); return no("no kernel instantiation for this format mix / head shape"); }
+  R.lds = std::max<size_t>(ptok_lds_bytes(ops.data(), ops.size(), D, G), 96 * 1024);   // > half a CU's LDS: one workgroup per CU
+  if (R.lds > 160 * 1024) { ops.clear(); return no("LDS"); }
+  // ---- device image: PtOp[n] | MvLaunch[n_mv] | PtAttn[n_attn]
+  uint32_t n_mv = 0, n_attn = 0;
+  std::vector<uint32_t> attn_index(ops.size(), kPtNone);
+  for (size_t i = 0; i < ops.size(); i++) {
+    if (ops[i].op.kind == PT_MV) ops[i].op.mv = n_mv++;
+    else { attn_index[i] = n_attn; ops[i].op.attn = n_attn++; }
+  }
+  uint32_t last_mv = kPtNone, first_mv = kPtNone;
+  for (size_t i = ops.size(); i-- > 0;) {
+    if (ops[i].op.kind == PT_MV) {
+      ops[i].op.next_mv = last_mv;
+      last_mv = (uint32_t)i;
+      first_mv = (uint32_t)i;
+      if (ops[i].op.in_kind == PT_IN_ATTN) ops[i].op.attn = attn_index[ops[i].op.attn];
+    }
+  }
+  const size_t off_mv = ops.size() * sizeof(PtOp), off_attn = off_mv + (size_t)n_mv * sizeof(MvLaunch);
+  const size_t img_bytes = off_attn + (size_t)n_attn * sizeof(PtAttn);
+  std::vector<uint8_t> img(img_bytes);
+  for (size_t i = 0; i < ops.size(); i++) {
+    std::memcpy(img.data() + i * sizeof(PtOp), &ops[i].op, sizeof(PtOp));
+    if (ops[i].op.kind == PT_MV) std::memcpy(img.data() + off_mv + (size_t)ops[i].op.mv * sizeof(MvLaunch), &ops[i].mv, sizeof(MvLaunch));
+    else std::memcpy(img.data() + off_attn + (size_t)ops[i].op.attn * sizeof(PtAttn), &ops[i].attn, sizeof(PtAttn));
+  }
+  int rc;
+  if ((rc = dev_alloc(c, (void**)&R.dev, img_bytes))) return rc;
+  const size_t sync_words = kPtSyncHeader + (size_t)(ncnt + 1) * kPtCntStride;
+  if ((rc = dev_alloc(c, (void**)&R.sync, sync_words * 4))) return rc;
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(R.dev, img.data(), img_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemset(R.sync, 0, sync_words * 4));
+  R.P.ops = reinterpret_cast<const PtOp*>(R.dev);
+  R.P.mv = reinterpret_cast<const MvLaunch*>(R.dev + off_mv);
+  R.P.attn = reinterpret_cast<const PtAttn*>(R.dev + off_attn);
+  R.P.sync = R.sync;
+  R.P.nops = (uint32_t)ops.size();
+  R.P.first_mv = first_mv;
+  R.weight_bytes = bytes;
+  R.usable = true;
+  return LGH_OK;
+}
+
+// One token on the persistent kernel: [embedding | advance + input conversion] -> the token kernel -> [arg-max].
+static int enqueue_token_pt(lgh_ctx* c, int mode) {
+  PtProg& R = c->pt[mode];
+  const lgh_model_desc& d = c->d;
+  int rc;
+  XqBuf* qh = xq_get(c, c->hidden, d.hidden_size);
+  if (!qh) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
+  if (c->first) {
+    if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
+           return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, qh->xq, R.first_nw, qh->ssq, c->stream);
+         })))
+      return rc;
+  } else {
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)d.hidden_size * 4, [&] {
+           return xq_quantize_launch(c->hidden, R.first_nw, qh->xq, qh->ssq, d.hidden_size, c->stream);
+         })))
+      return rc;
+  }
+  const uint64_t kv_bytes = (uint64_t)(c->l1 - c->l0) * 2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
+  if ((rc = run_k(c, LGH_K_TOKEN, LGH_SYM_PTOK, R.weight_bytes + kv_bytes, [&] {
+         return ptok_launch(R.P, R.mask, d.head_dim, d.num_heads / d.num_kv_heads, R.lds, c->stream);
+       })))
+    return rc;
+  if (c->last && mode == MODE_GREEDY) {
+    if ((rc = run_k(c, LGH_K_ARGMAX, LGH_SYM_ARGMAX, (uint64_t)d.vocab_size * 4, [&] {
+           return argmax_launch(c->logits, d.vocab_size, c->amax_v, c->amax_i, c->state, c->tok_log, c->stream);
+         })))
+      return rc;
+  }
+  for (auto& q : c->xqs) q.fresh = false;
+  return LGH_OK;
+}
+
 // Everything one token needs, in stream order.  Used eagerly and under graph capture.
 static int enqueue_token(lgh_ctx* c, int mode) {
+  if (c->pt[mode].usable) return enqueue_token_pt(c, mode);
   const lgh_model_desc& d = c->d;
   int rc;
   for (auto& q : c->xqs) q.fresh = false;   // the residual stream is (re)written in f32 now (embedding / previous stage)
@@ -690,7 +907,8 @@ static int step(lgh_ctx* c, int mode) {
   if (c->pos >= c->d.max_seq_len)  // the reference has no such check: OOB write past the KV capacity
     return fail(c, LGH_INVALID_ARGUMENT, "position " + std::to_string(c->pos) + " >= max_seq_len " + std::to_string(c->d.max_seq_len));
   int rc;
-  c->attn_direct = c->pos + 1 <= c->direct_attn_max_kv;   // the token at position pos attends to pos + 1 rows
+  // the token at position pos attends to pos + 1 rows (the persistent token kernel picks its splits on the device)
+  c->attn_direct = !c->pt[mode].usable && c->pos + 1 <= c->direct_attn_max_kv;
   if (c->profiling || (c->d.flags & LGH_FLAG_NO_GRAPH)) {
     if ((rc = enqueue_token(c, mode))) return rc;
     if (c->profiling && (rc = drain_prof(c))) return rc;
@@ -705,6 +923,12 @@ static int step(lgh_ctx* c, int mode) {
 
 // a chained launch whose grid barrier timed out raised this flag (bounded spins: the launch still ran to completion)
 static int check_chain(lgh_ctx* c) {
+  for (int m = 0; m < MODE_COUNT; m++) {   // a hand-off wait of the persistent token kernel that ran into its spin limit
+    if (!c->pt[m].usable) continue;
+    unsigned flag = 0;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->pt[m].sync + 16, 4, hipMemcpyDeviceToHost));
+    if (flag) return fail(c, LGH_OPERATION_FAILED, "a hand-off wait of the persistent token kernel timed out (code " + std::to_string(flag) + ")");
+  }
   if (!c->chain_sync) return LGH_OK;
   unsigned flag = 0;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->chain_sync + 576, 4, hipMemcpyDeviceToHost));
@@ -1160,6 +1384,15 @@ int lgh_finalize(lgh_ctx* c) {
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   c->finalized = true;
   c->pos = 0;
+  {  // the persistent token kernel's programs, one per graph mode (allocated here, never during a graph capture)
+    const uint32_t G = d.num_heads / d.num_kv_heads;
+    uint32_t smax = kNumCU / d.num_kv_heads;
+    c->pt_s_max = smax < 1 ? 1 : (smax > 32 ? 32 : smax);
+    if (const char* e = std::getenv("LGH_PT_ROWS_PER_SPLIT")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) c->pt_rows_per_split = (uint32_t)v; }
+    if ((rc = dev_alloc(c, (void**)&c->pt_part, pt_part_floats(d.num_kv_heads, c->pt_s_max, G, d.head_dim) * 4))) return rc;
+    for (int m = 0; m < MODE_COUNT; m++)
+      if ((rc = pt_build(c, m))) return rc;
+  }
   return warm_kernels(c);
 }
 
@@ -1194,7 +1427,7 @@ int lgh_forward(lgh_ctx* c, uint32_t token, float* logits_out) {
   if ((rc = step(c, MODE_FORWARD))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return LGH_OK;
+  return check_chain(c);
 }
 
 int lgh_prefill_token(lgh_ctx* c, uint32_t token) {

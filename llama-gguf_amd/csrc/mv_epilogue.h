@@ -17,9 +17,9 @@ struct MvEpiPre { float a, b; bool valid; };
 // `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
 template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, const float* xq_nw, uint32_t n_rows, uint32_t wg,
-                                                           uint32_t rows_per_wg, MvEpiPre& pre) {
+                                                           uint32_t rows_per_wg, MvEpiPre& pre, uint32_t tid = threadIdx.x) {
   if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
-    const uint32_t t = threadIdx.x, row = wg * rows_per_wg + t;
+    const uint32_t t = tid, row = wg * rows_per_wg + t;
     if (t < rows_per_wg && row < n_rows) {
       pre.a = coh_load<COH>(resid + row);   // the residual stream may have been written earlier in this very launch
       pre.b = xq_nw ? xq_nw[row] : 1.0f;   // the next consumer's norm weight, for the XQ image of the output
@@ -31,9 +31,10 @@ __device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float*
 // BEFORE the input vector and the weight tiles: a conditional load issued after them makes the compiler's wait for the
 // input vector conservative (it then also waits for the first tile to arrive from HBM).
 __device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos, const float* rope_cs, uint32_t head_dim,
-                                                          uint32_t n_rows, uint32_t wg, uint32_t rows_per_wg, MvEpiPre& pre) {
+                                                          uint32_t n_rows, uint32_t wg, uint32_t rows_per_wg, MvEpiPre& pre,
+                                                          uint32_t tid = threadIdx.x) {
   if (epi == EPI_ROPE_Q || epi == EPI_ROPE_K) {
-    const uint32_t rl = 2 * threadIdx.x, row = wg * rows_per_wg + rl;
+    const uint32_t rl = 2 * tid, row = wg * rows_per_wg + rl;
     if (rl < rows_per_wg && row < n_rows) {
       const uint32_t half = head_dim / 2, i = (row % head_dim) / 2;
       pre.a = rope_cs[((size_t)pos * half + i) * 2];
@@ -47,8 +48,9 @@ __device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos,
 // `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
 template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
-                                            const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false}) {
-  const uint32_t t = threadIdx.x;
+                                            const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false},
+                                            uint32_t tid = threadIdx.x) {
+  const uint32_t t = tid;
   const uint32_t rbase = wg * S.rows_per_wg;
   float inv = 1.0f;
   if (L.do_norm) {  // simd.rs:853-855: rms = sqrt(ss/n + eps); inv = 1/rms
@@ -72,12 +74,12 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     const float s = pre.valid ? pre.b : L.rope_cs[((size_t)pos * half + i) * 2 + 1];
     float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
     if (S.epi == EPI_ROPE_Q) {
-      S.out[row] = y0;
-      S.out[row + 1] = y1;
+      coh_store<COH>(S.out + row, y0);
+      coh_store<COH>(S.out + row + 1, y1);
     } else {
       float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
-      dst[0] = y0;
-      dst[1] = y1;
+      coh_store<COH>(dst, y0);
+      coh_store<COH>(dst + 1, y1);
     }
     return;
   }
@@ -100,7 +102,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     }
     case EPI_V_CACHE: {
       const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
-      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
+      coh_store<COH>(S.out + ((size_t)(row / d) * S.max_seq + pos) * d + (row % d), v0);
       break;
     }
     case EPI_MOE_SWIGLU: {
@@ -110,7 +112,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
         const float a = silu_f(g) * up;
         o[row] = a;
         uint8_t* xo = e == 0 ? S.xq_out : S.xq_out2;   // each expert's activation feeds its own down projection
-        if (xo) xq_store_chunk(xo, row >> 4, a);
+        if (xo) xq_store_chunk(xo, row >> 4, a, nullptr, 0.0f, tid);
       }
       break;
     }
@@ -131,7 +133,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   if (xq && has_out) {
     const float* nw = S.xq_nw;
     const float w = !nw ? 1.0f : (pre.valid && (S.epi == EPI_RESID || S.epi == EPI_MOE_DOWN)) ? pre.b : nw[row];
-    xq_store_chunk<COH>(xq, row >> 4, outv * w, S.xq_ssq, outv);
+    xq_store_chunk<COH>(xq, row >> 4, outv * w, S.xq_ssq, outv, tid);
   }
 }
 

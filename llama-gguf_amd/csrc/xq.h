@@ -51,8 +51,9 @@ __device__ __forceinline__ float coh_load(const float* p) {
 }
 
 template <bool COH = false>
-__device__ __forceinline__ void xq_store_chunk(uint8_t* xq, uint32_t chunk, float v, float* ssq_part = nullptr, float raw = 0.0f) {
-  const uint32_t l16 = threadIdx.x & 15;
+__device__ __forceinline__ void xq_store_chunk(uint8_t* xq, uint32_t chunk, float v, float* ssq_part = nullptr, float raw = 0.0f,
+                                               uint32_t tid = threadIdx.x) {
+  const uint32_t l16 = tid & 15;
   // max |v| and sum over the 16 lanes, in every lane (quad_perm x2, row_half_mirror, row_mirror)
   float amax = fabsf(v), sum = v;
   float sq = raw * raw;

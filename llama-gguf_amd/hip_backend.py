@@ -34,16 +34,17 @@ ABI_SYMBOLS = (
     "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get",
 )
 
-K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc")
+K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc", "token")
 K_COUNT = 16
-SYM_COUNT = 20
+SYM_COUNT = 24
 # kernel symbols as rocprofv3 prints them (LGH_SYM_* order)
 SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_kernel<16u, 1024>",
              "lgh::mv_kernel<2u, 512>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
-             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>")
+             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>", "lgh::ptok_kernel")
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
+FLAG_NO_PERSISTENT = 8   # decode as one launch per op instead of the persistent token kernel (LGH_NO_PERSISTENT=1 sets it too)
 FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
 
@@ -193,6 +194,8 @@ class HipGpuInference:
         d.layer_begin, d.layer_end = lb, le
         if os.environ.get("LGH_CHAIN_FFN", "") not in ("", "0"):
             flags |= FLAG_CHAIN_FFN
+        if os.environ.get("LGH_NO_PERSISTENT", "") not in ("", "0"):
+            flags |= FLAG_NO_PERSISTENT
         d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16)   # attn_direct: 64-row units, 255 = never
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
