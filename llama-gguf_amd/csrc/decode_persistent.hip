@@ -46,12 +46,32 @@ namespace lgh {
 constexpr int kPtDepth = PT_DEPTH;   // weight tiles a wave keeps in flight (registers)
 constexpr float kPtNegBig = -1e30f;
 
+// Diagnostic build only (-DLGH_STAMPS, `make stamps`): every wave of ONE workgroup records s_memrealtime (100 MHz) at the
+// phase boundaries of every op into a buffer nothing else reads (tools/pt_phases.py prints the profile).
+#ifdef LGH_STAMPS
+constexpr int kPtStampOps = 1024, kPtStampWg = 37;
+__device__ unsigned long long g_pt_stamps[kPtStampOps * kPtWaves * 8];
+hipError_t ptok_read_stamps(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_stamps), n * sizeof(unsigned long long));
+}
+#define PT_STAMP(i)                                                                                           \
+  do {                                                                                                        \
+    if (blockIdx.x == kPtStampWg && (threadIdx.x & 63) == 0 && op < (uint32_t)kPtStampOps)                     \
+      g_pt_stamps[(op * kPtWaves + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();         \
+  } while (0)
+#else
+#define PT_STAMP(i)
+#endif
+
 __device__ __forceinline__ unsigned pt_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float pt_ldf(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pt_stf(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Lanes l < n each wait until counter (first + l) has reached `target` (wrap-safe); the whole wave leaves together.
 __device__ __forceinline__ void pt_wait(unsigned* sync, uint32_t first, uint32_t n, unsigned target, uint32_t lane) {
+#ifdef PT_DEBUG_KNOBS
+  if (pt_ld(sync + 48) & 1u) return;
+#endif
   const unsigned* c = sync + kPtSyncHeader + (size_t)(first + (lane < n ? lane : 0)) * kPtCntStride;
   unsigned spins = 0;
   for (;;) {
@@ -168,7 +188,12 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
   if (base0 < pos) request(base0);
 
   // ---- wait for this kv head's q heads, k row and v row (wave 0 polls, the workgroup's barrier releases the rest)
-  if (wave == 0) {
+#ifdef PT_DEBUG_KNOBS
+  const bool nowait = (pt_ld(sync + 48) & 1u) != 0;
+#else
+  constexpr bool nowait = false;
+#endif
+  if (wave == 0 && !nowait) {
     const unsigned target = (epoch + 1u) * (unsigned)D;
     const uint32_t c = lane < (uint32_t)G ? A.in_cnt + kvh * G + lane : lane == (uint32_t)G ? A.in_cnt + A.n_heads + kvh : A.in_cnt + A.n_heads + n_kv + kvh;
     const unsigned* cp = sync + kPtSyncHeader + (size_t)c * kPtCntStride;
@@ -363,10 +388,12 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     const uint32_t lane = tid & 63;
 #endif
     const uint32_t n = lane & 15, c = lane >> 4;
+    PT_STAMP(0);
     if (O.kind == PT_ATTN) {
 #ifndef PT_EXP_NOATTN
       pt_attention<D, G>(P.attn[O.attn], bid, epoch, sync, smem8, tid);
 #endif
+      PT_STAMP(7);
       continue;
     }
     const MvLaunch& L = P.mv[O.mv];
@@ -398,6 +425,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
 #endif
       } else {
         if (O.in_kind == PT_IN_XQ) pt_wait(sync, O.in_cnt + gc.blk0, gc.nblk_w, (epoch + 1u) * 256u, lane);
+        PT_STAMP(1);
         const uint8_t* xg = S.pass[0].xq + (size_t)gc.blk0 * kXqRecord;
         for (uint32_t b = 0; b < gc.nblk_w; b++) {     // 1024 B + 256 B per record by LDS-DMA (agent-scope loads)
           const uint8_t* src = xg + b * kXqRecord;
@@ -421,6 +449,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the records (and every prefetched tile behind them) have landed
     if (O.in_kind == PT_IN_ATTN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PT_STAMP(2);
 
     // ---- this wave's tiles of the op: consume one, put the next one of the flat stream in flight
     float acc = 0.0f;
@@ -444,15 +473,19 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     for (int j = 0; j < kPtDepth - 1; j++)
       if ((uint32_t)j < rem) { consume(meta[j], buf[j]); issue_one(buf[j], meta[j], lane); }
 
+    PT_STAMP(3);
     if (nrm) {
       ss_w = wave_sum_to_lane63(ss_w);
       if (lane == 63) ssq[wave] = ss_w;
     }
     __syncthreads();
+    PT_STAMP(4);
 #ifndef PT_EXP_NOEPI
     mv_epilogue<true>(L, S, gc.wg, red, ssq, gc.T, epi_pre, tid);
 #endif
+    PT_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores drained (and the ring's tiles landed)
+    PT_STAMP(6);
     __syncthreads();
     // ---- signal: the rows this workgroup produced, per signal group of the segment's output
     const uint32_t oc = O.out_cnt[gc.seg];
@@ -467,6 +500,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
         }
       }
     }
+    PT_STAMP(7);
     // the ring starts every op at slot 0: rotate the consumed slots to the back (their loads have landed)
 #pragma unroll
     for (int r = 0; r < kPtDepth - 1; r++) {

@@ -752,6 +752,10 @@ static int pt_build(lgh_ctx* c, int mode) {
   if ((rc = dev_alloc(c, (void**)&R.sync, sync_words * 4))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(R.dev, img.data(), img_bytes, hipMemcpyHostToDevice));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemset(R.sync, 0, sync_words * 4));
+  if (const char* e = std::getenv("LGH_PT_DEBUG")) {   // timing experiments (diagnostic builds read the word): bit 0 = never wait
+    const unsigned v = (unsigned)std::atoi(e);
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(R.sync + 48, &v, 4, hipMemcpyHostToDevice));
+  }
   R.P.ops = reinterpret_cast<const PtOp*>(R.dev);
   R.P.mv = reinterpret_cast<const MvLaunch*>(R.dev + off_mv);
   R.P.attn = reinterpret_cast<const PtAttn*>(R.dev + off_attn);
