@@ -88,10 +88,15 @@ enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
   LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
   LGH_FLAG_EXACT_PREFILL = 1u << 2,  /* lgh_prefill_batch feeds the tokens one by one (f32 throughout) instead of the batched f16 GEMM path */
-  LGH_FLAG_NO_PERSISTENT = 1u << 3,  /* decode as one launch per op (hipGraph of ~6 kernels per layer) instead of the persistent token kernel */
+  LGH_FLAG_PERSISTENT = 1u << 3,     /* decode with the persistent token kernel (one launch per token, data-flow hand-offs between ops;
+                                        csrc/decode_persistent.hip) instead of the hipGraph of one launch per op.  Correct and tested, but
+                                        MEASURED SLOWER on MI355X (2.6 vs 1.6 ms per Llama-3-8B token), so it is opt-in */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
-  LGH_FLAG_ATTN_DIRECT_SHIFT = 16    /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
+  LGH_FLAG_ATTN_DIRECT_SHIFT = 16,   /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
                                         per kv head, no split + combine pair); 0 = the tuned default, 255 = never */
+  LGH_FLAG_ATTN_MERGE_SHIFT = 24     /* bits 24..31: contexts of up to 64 * n rows (beyond the single-launch range) run 8 KV splits per kv head
+                                        and the output projection's waves merge the split partials themselves (no combine launch);
+                                        0 = the default = never (measured slower than the combine launch, engine.hip), 255 = never */
 };
 
 typedef struct lgh_ctx lgh_ctx;

@@ -141,6 +141,12 @@ struct MvLaunch {
   const float* ssq_part;     // int8-MFMA kernel with do_norm: partial sums of x^2 left by the producer of x
   uint32_t n_ssq_part;
   uint32_t dbg_slot;         // diagnostic builds: launch sequence number mod 64 (span stamps)
+  // int8-MFMA kernel, optional: the input vector is the decode attention's output, taken straight from the split partials
+  // (attention.hip: part_ml [(kv head, split, g)][2] = m, l; part_acc [(kv head, split, g)][D]) — every wave merges the heads
+  // of its own k-slice and converts them to XQ in LDS, so no combine kernel runs between attention and the output projection
+  const float* attn_ml;
+  const float* attn_acc;
+  uint32_t attn_splits, attn_g, attn_dshift;   // splits per kv head, query heads per kv head, log2(head_dim)
   MvSeg seg[3];
 };
 

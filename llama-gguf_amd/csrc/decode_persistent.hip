@@ -49,7 +49,7 @@ constexpr float kPtNegBig = -1e30f;
 // Diagnostic build only (-DLGH_STAMPS, `make stamps`): every wave of ONE workgroup records s_memrealtime (100 MHz) at the
 // phase boundaries of every op into a buffer nothing else reads (tools/pt_phases.py prints the profile).
 #ifdef LGH_STAMPS
-constexpr int kPtStampOps = 1024, kPtStampWg = 37;
+constexpr int kPtStampOps = 1024, kPtStampWg = 1;
 __device__ unsigned long long g_pt_stamps[kPtStampOps * kPtWaves * 8];
 hipError_t ptok_read_stamps(unsigned long long* host, size_t n) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pt_stamps), n * sizeof(unsigned long long));
@@ -57,7 +57,7 @@ hipError_t ptok_read_stamps(unsigned long long* host, size_t n) {
 #define PT_STAMP(i)                                                                                           \
   do {                                                                                                        \
     if (blockIdx.x == kPtStampWg && (threadIdx.x & 63) == 0 && op < (uint32_t)kPtStampOps)                     \
-      g_pt_stamps[(op * kPtWaves + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();         \
+      g_pt_stamps[(op * kPtWaves + ((threadIdx.x >> 6) & 7)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime();         \
   } while (0)
 #else
 #define PT_STAMP(i)
@@ -115,7 +115,7 @@ __device__ __forceinline__ void pt_geo(const PtOp& O, const MvLaunch& L, uint32_
   if (!g.in_op) return;
   const uint32_t s = (uint32_t)(bid >= (O.wbpack & 0xFFFFu)) + (uint32_t)(bid >= (O.wbpack >> 16));
   const MvSeg& S = L.seg[s];
-  const uint32_t T = O.geom & 0xFFu, G = (O.geom >> 8) & 0xFFu, nbw = (O.geom >> 16) & 0x7FFFu;
+  const uint32_t T = O.geom & 0xFFu, G = (O.geom >> 8) & 0xFFu, nbw = (O.geom >> 16) & 0x3FFFu;
   const uint32_t nblk = O.geom2 & 0xFFFFu, Rg = O.geom2 >> 16;
   g.seg = s; g.T = T; g.Rg = Rg; g.nblk = nblk;
   g.rpw = 16u * Rg * G;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void pt_geo(const PtOp& O, const MvLaunch& L, uint32_
 #define PT_ATTN_INLINE __forceinline__
 #endif
 template <int D, int G>
-__device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsigned epoch, unsigned* sync, uint8_t* smem8, uint32_t tid) {
+__device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsigned epoch, unsigned* sync, uint8_t* smem8, uint32_t tid, uint32_t op) {
   constexpr int NW = kPtWaves;
   constexpr int LPR = D / 4;       // lanes per row
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
@@ -161,8 +161,8 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
     if (tid == 0) pt_signal(sync, A.out_cnt + kvh, 1u);
     return;
   }
-  float (*s_ml)[G][2] = reinterpret_cast<float (*)[G][2]>(smem8);
-  float (*s_acc)[G][D] = reinterpret_cast<float (*)[G][D]>(smem8 + sizeof(float) * NW * G * 2);
+  float (*s_ml)[G][2] = reinterpret_cast<float (*)[G][2]>(smem8 + A.lds_off);   // (a region of its own: the mat-vec ops' x / partial-sum regions stay live)
+  float (*s_acc)[G][D] = reinterpret_cast<float (*)[G][D]>(smem8 + A.lds_off + sizeof(float) * NW * G * 2);
 
   const uint32_t sub = lane / LPR, li = lane % LPR;
   const float* kbase = A.kc + (size_t)kvh * A.max_seq * D + li * 4;
@@ -209,7 +209,9 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
       }
     }
   }
+  PT_STAMP(1);
   __syncthreads();
+  PT_STAMP(2);
 
   f32x4 qv[G];
 #pragma unroll
@@ -258,6 +260,7 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
     step(sub == 0, k4, v4);
   }
 
+  PT_STAMP(3);
   // merge the RPW row slots of the wave (lanes with equal li hold the same output dims)
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -282,6 +285,7 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
     }
   }
   __syncthreads();
+  PT_STAMP(4);
   // merge the waves and publish the split's partial: ml[G][2], acc[G][D]
   float* part = A.part + ((size_t)kvh * A.s_max + sp) * (size_t)(G * (D + 2));
   for (uint32_t e = tid; e < (uint32_t)(G * D); e += NW * 64) {
@@ -299,38 +303,66 @@ __device__ PT_ATTN_INLINE void pt_attention(const PtAttn& A, uint32_t bid, unsig
     pt_stf(part + 2 * G + g * D + dim, a);
     if (dim == 0) { pt_stf(part + g * 2, mn); pt_stf(part + g * 2 + 1, lsum); }
   }
+  PT_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have left
+  PT_STAMP(6);
   __syncthreads();
   if (tid == 0) pt_signal(sync, A.out_cnt + kvh, 1u);
 }
 
 // The consumer side of attention: a wo wave merges the split partials of the heads in ITS k-slice (elements
 // [blk0 * 256, (blk0 + nblk_w) * 256) of the attention output) and writes them as XQ records into its LDS region.
+// Two memory round trips in all: the splits' (m, l) of the slice's heads, then every accumulator the slice needs, four
+// splits at a time, all requested before the first one is used.
 template <int D, int G>
 __device__ __forceinline__ void pt_gather_attn(const PtAttn& A, uint32_t blk0, uint32_t nblk_w, unsigned epoch, unsigned* sync,
-                                               uint8_t* xrec, uint32_t lane) {
-  const uint32_t n_splits = pt_splits(A, __builtin_amdgcn_readfirstlane((uint32_t)*A.pos) + 1);
+                                               uint8_t* xrec, uint32_t lane, uint32_t kv_len) {
+  const uint32_t n_splits = pt_splits(A, kv_len);
   const uint32_t e0 = blk0 * 256, e1 = e0 + nblk_w * 256;
   const uint32_t kv0 = e0 / (D * G), kv1 = (e1 - 1) / (D * G);
   pt_wait(sync, A.out_cnt + kv0, kv1 - kv0 + 1, (epoch + 1u) * A.s_max, lane);
-  const size_t pstride = (size_t)(G * (D + 2));
-  for (uint32_t it = 0; it < nblk_w * 4; it++) {       // 64 consecutive elements: one head (64 divides D)
-    const uint32_t e = e0 + it * 64 + lane;
-    const uint32_t h = e / D, dim = e % D, kvh = h / G, g = h % G;
-    const float* p0 = A.part + (size_t)kvh * A.s_max * pstride;
-    // the splits' (m, l) of this head: lane s holds split s; then every lane needs all of them
-    float ms = kPtNegBig, ls = 0.0f;
-    if (lane < n_splits) { ms = pt_ldf(p0 + lane * pstride + g * 2); ls = pt_ldf(p0 + lane * pstride + g * 2 + 1); }
-    const float mn = wave_max(ms);
-    const float f = expf(ms - mn);
-    const float lsum = wave_sum(ls * f);
-    float a = 0.0f;
-    for (uint32_t s = 0; s < n_splits; s++) {
-      const float fs = __shfl(f, (int)s, 64);
-      a = __builtin_fmaf(pt_ldf(p0 + s * pstride + 2 * G + g * D + dim), fs, a);
+  constexpr uint32_t pstride = (uint32_t)(G * (D + 2));
+  const uint32_t nit = nblk_w * 4;                      // 64 consecutive elements per step: one head (64 divides D)
+  for (uint32_t it0 = 0; it0 < nit; it0 += 4) {         // four steps (256 elements) at a time
+    // the (m, l) of step j's head, split s = lane & 31 (lanes >= 32 mirror the lower half; s_max <= 32)
+    float fw[4], linv[4];
+    float ms[4], ls[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t h = (e0 + (it0 + j) * 64) / D, kvh = h / G, g = h % G, s = lane & 31;
+      const float* p = A.part + ((size_t)kvh * A.s_max + (s < n_splits ? s : 0)) * pstride + g * 2;
+      ms[j] = pt_ldf(p);
+      ls[j] = pt_ldf(p + 1);
     }
-    const float o = a * (1.0f / lsum);                 // simd.rs:718-720: multiply by 1/sum
-    xq_store_chunk<false>(xrec, it * 4 + (lane >> 4), o, nullptr, 0.0f, lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const bool live = (lane & 31) < n_splits;
+      const float m = live ? ms[j] : kPtNegBig;
+      const float mn = wave_max(m);
+      fw[j] = live ? expf(m - mn) : 0.0f;
+      const float lsum = wave_sum(lane < 32 ? ls[j] * fw[j] : 0.0f);
+      linv[j] = 1.0f / lsum;                            // simd.rs:718-720: multiply by 1/sum
+    }
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t s0 = 0; s0 < n_splits; s0 += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t e = e0 + (it0 + j) * 64 + lane, h = e / D, dim = e % D, kvh = h / G, g = h % G;
+        const float* p0 = A.part + (size_t)kvh * A.s_max * pstride + 2 * G + g * D + dim;
+#pragma unroll
+        for (int t = 0; t < 4; t++) v[j][t] = pt_ldf(p0 + (size_t)(s0 + t < n_splits ? s0 + t : s0) * pstride);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+          const float fs = __shfl(fw[j], (int)(s0 + t), 64);
+          a[j] = __builtin_fmaf(v[j][t], s0 + t < n_splits ? fs : 0.0f, a[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) xq_store_chunk<false>(xrec, (it0 + j) * 4 + (lane >> 4), a[j] * linv[j], nullptr, 0.0f, lane);
   }
 }
 
@@ -391,7 +423,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     PT_STAMP(0);
     if (O.kind == PT_ATTN) {
 #ifndef PT_EXP_NOATTN
-      pt_attention<D, G>(P.attn[O.attn], bid, epoch, sync, smem8, tid);
+      pt_attention<D, G>(P.attn[O.attn], bid, epoch, sync, smem8, tid, op);
 #endif
       PT_STAMP(7);
       continue;
@@ -401,7 +433,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     pt_geo(O, L, bid, wave, gc);
     if (!gc.in_op) continue;
     const MvSeg& S = L.seg[gc.seg];
-    const uint32_t nbw = (O.geom >> 16) & 0x7FFFu;
+    const uint32_t nbw = (O.geom >> 16) & 0x3FFFu;
     const bool nrm = (O.geom >> 31) != 0;
     uint8_t* xrec = smem8 + wave * nbw * kXqRecord;
     const uint32_t xrec_lds = lds_base + wave * nbw * kXqRecord;
@@ -421,7 +453,7 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     if (gc.nitems) {
       if (O.in_kind == PT_IN_ATTN) {
 #ifndef PT_EXP_NOGATHER
-        pt_gather_attn<D, G>(P.attn[O.attn], gc.blk0, gc.nblk_w, epoch, sync, xrec, lane);
+        pt_gather_attn<D, G>(P.attn[O.attn], gc.blk0, gc.nblk_w, epoch, sync, xrec, lane, __builtin_amdgcn_readfirstlane((uint32_t)*L.pos) + 1);
 #endif
       } else {
         if (O.in_kind == PT_IN_XQ) pt_wait(sync, O.in_cnt + gc.blk0, gc.nblk_w, (epoch + 1u) * 256u, lane);
@@ -484,11 +516,15 @@ __global__ void __launch_bounds__(kPtWaves * 64) ptok_kernel(const PtProgram P) 
     mv_epilogue<true>(L, S, gc.wg, red, ssq, gc.T, epi_pre, tid);
 #endif
     PT_STAMP(5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores drained (and the ring's tiles landed)
-    PT_STAMP(6);
-    __syncthreads();
-    // ---- signal: the rows this workgroup produced, per signal group of the segment's output
+    // ---- signal: the rows this workgroup produced, per signal group of the segment's output.  Only the waves that ran the
+    // epilogue have stores to drain; the others are already on their way to the next op (the partial-sum buffers alternate
+    // between ops, so nothing they write next is still being read here).
     const uint32_t oc = O.out_cnt[gc.seg];
+    const uint32_t epi_threads = (S.epi == EPI_ROPE_Q || S.epi == EPI_ROPE_K) ? gc.rpw / 2 : gc.rpw;
+    const bool many = epi_threads > 64;
+    if (oc != kPtNone && (many || wave == 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores have left
+    PT_STAMP(6);
+    if (oc != kPtNone && many) __syncthreads();
     if (oc != kPtNone && wave == 0) {
       const uint32_t sh = O.out_shift[gc.seg];
       const uint32_t r0 = gc.wg * gc.rpw, r1 = min(r0 + gc.rpw, S.n_rows);
@@ -530,11 +566,21 @@ size_t pt_part_floats(uint32_t n_kv, uint32_t s_max, uint32_t group, uint32_t he
   return (size_t)n_kv * s_max * group * (head_dim + 2);
 }
 
-size_t ptok_lds_bytes(const PtHostOp* ops, size_t n, uint32_t head_dim, uint32_t group) {
-  size_t lds = (size_t)kPtWaves * group * (head_dim + 2) * 4;   // attention: per-wave partial states
+size_t ptok_layout_lds(PtHostOp* ops, size_t n, uint32_t head_dim, uint32_t group) {
+  size_t x_max = 0, red_max = 0;
   for (size_t i = 0; i < n; i++)
-    if (ops[i].op.kind == PT_MV) lds = std::max(lds, (size_t)ops[i].op.lds_red_off + (size_t)(ops[i].op.red_floats + 16) * 4);
-  return (lds + 255) / 256 * 256;
+    if (ops[i].op.kind == PT_MV) {
+      x_max = std::max(x_max, (size_t)ops[i].op.lds_red_off);                       // = waves x blocks per k-slice x record bytes
+      red_max = std::max(red_max, (size_t)(ops[i].op.red_floats + 16) * 4);
+    }
+  x_max = (x_max + 255) / 256 * 256;
+  red_max = (red_max + 255) / 256 * 256;
+  uint32_t parity = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (ops[i].op.kind == PT_MV) { ops[i].op.lds_red_off = (uint32_t)(x_max + parity * red_max); parity ^= 1u; }
+    else ops[i].attn.lds_off = (uint32_t)(x_max + 2 * red_max);
+  }
+  return x_max + 2 * red_max + (size_t)kPtWaves * group * (head_dim + 2) * 4 + 256;
 }
 
 uint32_t ptok_mask(const PtHostOp* ops, size_t n) {

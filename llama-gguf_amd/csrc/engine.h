@@ -89,8 +89,10 @@ struct lgh_ctx {
   bool finalized = false;
   bool profiling = false;
   std::string err;
-  hipGraphExec_t graph[lgh::MODE_COUNT][2] = {};   // [mode][attention variant: 0 split + combine, 1 single launch (short context)]
+  hipGraphExec_t graph[lgh::MODE_COUNT][3] = {};   // [mode][attention variant: 0 split + combine, 1 single launch (short context), 2 split + merge in wo]
   bool attn_direct = false;                        // variant of the token being enqueued (chosen by the host-side position)
+  bool attn_merge = false;                         // ... 8 splits, merged by the output projection's waves (no combine kernel)
+  uint32_t merge_attn_max_kv = 0, merge_splits = 8;
   uint32_t direct_attn_max_kv = 0;                 // contexts up to this many rows take the single-launch attention
   uint64_t graph_nodes = 0;
   // accounting
@@ -132,6 +134,10 @@ struct SegSpec {
   const float* resid = nullptr;
   const float* bias = nullptr;
   const float* moe_w = nullptr;
+  // the input vector is the attention output, merged from split partials inside the kernel (MvLaunch::attn_*)
+  const float* attn_ml = nullptr;
+  const float* attn_acc = nullptr;
+  uint32_t attn_splits = 0;
 };
 
 int fail(lgh_ctx* c, int status, const std::string& msg);

@@ -64,6 +64,12 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
 // otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
 // 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
 constexpr uint32_t kDirectAttnDefaultKv = 64;
+// Optional (flag bits 24..31): contexts up to 64 * n rows run the decode attention with 8 splits per kv head and let the output
+// projection's waves merge the split partials themselves (matvec_mfma.hip: mvq_gather_attn) — one graph node fewer per layer.
+// MEASURED SLOWER on Llama-3-8B at kv 134..270 (577 vs 612 tokens/s): every one of the 256 output-projection workgroups
+// repeats the merge of all 32 heads (80 extra load instructions per wave, +5 us per launch), which costs more than the
+// 4.98 us combine node it removes.  Off by default.
+constexpr uint32_t kMergeAttnDefaultKv = 0;
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -287,7 +293,11 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
       if (mfma) {   // the input vector as XQ records: left by its producer, or converted here
         XqBuf* q = xq_get(c, sp.x[p], k);
         if (!q) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
-        if (!q->fresh || q->tag != norm_w) {
+        if (sp.attn_acc) {   // merged from the attention's split partials inside the kernel: no image in memory at all
+          L.attn_ml = sp.attn_ml; L.attn_acc = sp.attn_acc; L.attn_splits = sp.attn_splits;
+          L.attn_g = c->d.num_heads / c->d.num_kv_heads;
+          L.attn_dshift = c->d.head_dim == 64 ? 6u : 7u;
+        } else if (!q->fresh || q->tag != norm_w) {
           int rq = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)k * 4, [&] {
             return xq_quantize_launch(sp.x[p], norm_w, q->xq, norm_w ? q->ssq : nullptr, k, c->stream);
           });
@@ -476,6 +486,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   // ---- attention_cached (ops.rs:1479-1537)
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
+  const bool merge = c->attn_merge && !c->attn_direct && mfma_type(Lw.wo.type);
   if (c->attn_direct) {
     XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
@@ -485,6 +496,14 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
       return rc;
     if (qa) { qa->fresh = true; qa->tag = nullptr; }
     else xq_stale(c, c->attn_out);
+  } else if (merge) {
+    // few splits, merged by the output projection's own waves (MvLaunch::attn_*): no combine launch
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
+                              c->state + ST_POS, 0, c->merge_splits, c->part_ml, c->part_acc, c->stream);
+         })))
+      return rc;
+    xq_stale(c, c->attn_out);
   } else {
   if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
@@ -520,7 +539,13 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
     return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3);
   }
-  if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
+  if (merge) {
+    SegSpec sp;
+    sp.W[0] = &Lw.wo; sp.x[0] = c->attn_out; sp.epi = EPI_RESID; sp.out = c->hidden; sp.resid = c->hidden; sp.bias = Lw.bo;
+    sp.xq_next = ffn_mfma ? 2 : 0; sp.xq_next_nw = Lw.ffn_norm;
+    sp.attn_ml = c->part_ml; sp.attn_acc = c->part_acc; sp.attn_splits = c->merge_splits;
+    if ((rc = launch_mv(c, LGH_K_WO, &sp, 1, nullptr, Lw.wo.k))) return rc;
+  } else if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
   if (c->profiling) {  // an EMPTY event bracket in mid-stream: what the measurement itself adds to every sample (at the
     // head of a token, on an idle stream, the same bracket reads differently from run to run)
     if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
@@ -598,7 +623,7 @@ static int pt_build(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   const uint32_t H = d.hidden_size, D = d.head_dim, NH = d.num_heads, NKV = d.num_kv_heads, G = NH / NKV;
   auto no = [&](const std::string& why) { R.why = why; return LGH_OK; };
-  if (d.flags & (LGH_FLAG_NO_PERSISTENT | LGH_FLAG_CHAIN_FFN)) return no("disabled by flag");
+  if (!(d.flags & LGH_FLAG_PERSISTENT) || (d.flags & LGH_FLAG_CHAIN_FFN)) return no("not requested (LGH_FLAG_PERSISTENT)");
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < kNumCU) return no("device has fewer than 256 CUs");
   if (H % 256 || (NH * D) % 256 || d.use_neox_rope || c->l0 >= c->l1) return no("shape");
@@ -720,7 +745,7 @@ static int pt_build(lgh_ctx* c, int mode) {
   if (bad) { ops.clear(); return no("an op's geometry does not fit the persistent kernel"); }
   R.mask = ptok_mask(ops.data(), ops.size());
   if (!R.mask || !ptok_supported(R.mask, D, G)) { ops.clear(); return no("no kernel instantiation for this format mix / head shape"); }
-  R.lds = std::max<size_t>(ptok_lds_bytes(ops.data(), ops.size(), D, G), 96 * 1024);   // > half a CU's LDS: one workgroup per CU
+  R.lds = std::max<size_t>(ptok_layout_lds(ops.data(), ops.size(), D, G), 96 * 1024);   // > half a CU's LDS: one workgroup per CU
   if (R.lds > 160 * 1024) { ops.clear(); return no("LDS"); }
   // ---- device image: PtOp[n] | MvLaunch[n_mv] | PtAttn[n_attn]
   uint32_t n_mv = 0, n_attn = 0;
@@ -862,15 +887,17 @@ static int check_chain(lgh_ctx* c);
 static int warm_kernels(lgh_ctx* c) {
   if (c->d.flags & LGH_FLAG_NO_GRAPH) return LGH_OK;
   int rc = LGH_OK;
-  const bool keep_direct = c->attn_direct;
-  for (int v = 0; v < 2 && !rc; v++) {
-    if (v == 1 && c->direct_attn_max_kv == 0) break;
+  const bool keep_direct = c->attn_direct, keep_merge = c->attn_merge;
+  for (int v = 0; v < 3 && !rc; v++) {
+    if ((v == 1 && c->direct_attn_max_kv == 0) || (v == 2 && c->merge_attn_max_kv == 0)) continue;
     c->attn_direct = v == 1;
+    c->attn_merge = v == 2;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
     for (int mode : {c->last ? MODE_GREEDY : MODE_PREFILL, MODE_PREFILL})   // the last stage: with and without the output head
       if (!rc) rc = enqueue_token(c, mode);
   }
   c->attn_direct = keep_direct;
+  c->attn_merge = keep_merge;
   for (auto& q : c->xqs) q.fresh = false;
   if (rc) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
@@ -879,7 +906,7 @@ static int warm_kernels(lgh_ctx* c) {
 }
 
 static int ensure_graph(lgh_ctx* c, int mode) {
-  const int var = c->attn_direct ? 1 : 0;
+  const int var = c->attn_direct ? 1 : c->attn_merge ? 2 : 0;
   if (c->graph[mode][var]) return LGH_OK;
   hipGraph_t g = nullptr;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
@@ -913,12 +940,13 @@ static int step(lgh_ctx* c, int mode) {
   int rc;
   // the token at position pos attends to pos + 1 rows (the persistent token kernel picks its splits on the device)
   c->attn_direct = !c->pt[mode].usable && c->pos + 1 <= c->direct_attn_max_kv;
+  c->attn_merge = !c->pt[mode].usable && !c->attn_direct && c->pos + 1 <= c->merge_attn_max_kv;
   if (c->profiling || (c->d.flags & LGH_FLAG_NO_GRAPH)) {
     if ((rc = enqueue_token(c, mode))) return rc;
     if (c->profiling && (rc = drain_prof(c))) return rc;
   } else {
     if ((rc = ensure_graph(c, mode))) return rc;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode][c->attn_direct ? 1 : 0], c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode][c->attn_direct ? 1 : c->attn_merge ? 2 : 0], c->stream));
   }
   c->pos += 1;
   c->stats.tokens_processed += 1;
@@ -1176,6 +1204,13 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   c->n_splits = splits;
   const uint32_t dsel = (d.flags >> LGH_FLAG_ATTN_DIRECT_SHIFT) & 0xFFu;
   c->direct_attn_max_kv = dsel == 255 ? 0 : dsel ? dsel * 64 : kDirectAttnDefaultKv;
+  // split + merge-in-wo: contexts up to 64 * n rows (bits 24..31; 0 = the tuned default, 255 = never).  Needs the output
+  // projection on the matrix cores (checked per layer) and 64 | head_dim.
+  const uint32_t msel = (d.flags >> LGH_FLAG_ATTN_MERGE_SHIFT) & 0xFFu;
+  c->merge_attn_max_kv = msel == 255 ? 0 : msel ? msel * 64 : kMergeAttnDefaultKv;
+  if (c->merge_attn_max_kv && c->merge_attn_max_kv <= c->direct_attn_max_kv) c->merge_attn_max_kv = 0;
+  if ((d.num_heads * d.head_dim) % 256 || d.head_dim % 64 || (d.flags & LGH_FLAG_CHAIN_FFN)) c->merge_attn_max_kv = 0;
+  if (const char* e = std::getenv("LGH_MERGE_SPLITS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) c->merge_splits = (uint32_t)v; }
   *out = c;
   return LGH_OK;
 }
@@ -1405,7 +1440,7 @@ void lgh_destroy(lgh_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int m = 0; m < MODE_COUNT; m++)
-    for (int v = 0; v < 2; v++)
+    for (int v = 0; v < 3; v++)
       if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
@@ -1609,7 +1644,7 @@ int lgh_set_stream(lgh_ctx* c, void* s) {
   hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
   if (ns != c->stream) {
     for (int m = 0; m < MODE_COUNT; m++)
-      for (int v = 0; v < 2; v++)
+      for (int v = 0; v < 3; v++)
         if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
   }
   c->stream = ns;

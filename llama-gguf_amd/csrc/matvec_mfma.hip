@@ -308,6 +308,56 @@ hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, floa
   return hipGetLastError();
 }
 
+// The decode attention's split partials -> this wave's k-slice of the attention output, as XQ records in its LDS region
+// (MvLaunch::attn_*).  Elements [blk0 * 256, (blk0 + nblk_w) * 256); 64 consecutive elements belong to one head (64 divides
+// head_dim).  Per 512 elements ONE memory round trip: the (m, l) of every (step, split) and all accumulators are requested
+// before any is used (up to 8 splits; attention.hip's layout part_ml [(kv head, split, g)][2], part_acc [(kv head, split, g)][D]);
+// out = sum_s acc_s e^(m_s - m*) / sum_s l_s e^(m_s - m*), as attn_combine_kernel computes it.
+constexpr uint32_t kMergeMaxSplits = 8;
+__device__ __forceinline__ void mvq_gather_attn(const float* __restrict__ pml, const float* __restrict__ pacc, uint32_t S, uint32_t G,
+                                                uint32_t dshift, uint32_t blk0, uint32_t nblk_w, uint8_t* xrec, uint32_t lane) {
+  const uint32_t D = 1u << dshift, e0 = blk0 * 256;
+  for (uint32_t it0 = 0; it0 < nblk_w * 4; it0 += 8) {
+    const uint32_t nst = min(8u, nblk_w * 4 - it0);    // steps of 64 elements in this group (4 or 8)
+    float ms[8], ls[8], v[8][kMergeMaxSplits];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t jj = (uint32_t)j < nst ? (uint32_t)j : 0u;
+      const uint32_t e = e0 + (it0 + jj) * 64 + lane, h = e >> dshift, dim = e & (D - 1), kvh = h / G, g = h - kvh * G;
+      const uint32_t sl = lane & 7;
+      const size_t im = ((size_t)kvh * S + (sl < S ? sl : 0)) * G + g;
+      ms[j] = pml[im * 2];
+      ls[j] = pml[im * 2 + 1];
+#pragma unroll
+      for (uint32_t t = 0; t < kMergeMaxSplits; t++)
+        v[j][t] = pacc[((((size_t)kvh * S + (t < S ? t : 0)) * G + g) << dshift) + dim];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if ((uint32_t)j < nst) {
+        // lanes 8i .. 8i+7 hold splits 0..7 of this step's head: max / sum within the group of 8 by DPP
+        const bool live = (lane & 7) < S;
+        float m = live ? ms[j] : -1e30f;
+        float mn = fmaxf(m, dpp_f<0xB1>(m));
+        mn = fmaxf(mn, dpp_f<0x4E>(mn));
+        mn = fmaxf(mn, dpp_f<0x141>(mn));                 // row_half_mirror: lanes i <-> 7 - i within each 8
+        const float f = live ? expf(m - mn) : 0.0f;
+        float lsum = ls[j] * f;
+        lsum += dpp_f<0xB1>(lsum);
+        lsum += dpp_f<0x4E>(lsum);
+        lsum += dpp_f<0x141>(lsum);
+        float a = 0.0f;
+#pragma unroll
+        for (uint32_t t = 0; t < kMergeMaxSplits; t++) {
+          const float ft = __shfl(f, (int)((lane & ~7u) + t), 64);   // split t's weight, from this lane's own group of 8
+          a = __builtin_fmaf(v[j][t], t < S ? ft : 0.0f, a);
+        }
+        xq_store_chunk<false>(xrec, (it0 + j) * 4 + (lane >> 4), a * (1.0f / lsum), nullptr, 0.0f, lane);   // simd.rs:718-720: x 1/sum
+      }
+    }
+  }
+}
+
 constexpr int kWaves = 8;   // waves per workgroup: 2 per SIMD, 256 VGPRs each
 constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x 8 waves = 72 KiB per CU)
 
@@ -328,7 +378,7 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 // MASK: the formats (1 << F_*) the instantiation handles; with more than one the segment's type decides at run time
 // COH: the op runs inside a chain (mvq_chain_kernel): its inputs may have been written earlier in the same launch by
 // workgroups on other XCDs, and its outputs are read later in the same launch — agent-scope loads / write-through stores.
-template <uint32_t MASK, bool COH>
+template <uint32_t MASK, bool COH, bool ATTN = false>
 __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                          uint32_t lds_red_off, const MvLaunch& L, uint8_t* smem8) {
   // the position word (RoPE epilogues): its scalar load goes out with the very first kernarg loads, no wait here
@@ -347,8 +397,9 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   auto is = [&](int f) { return ((MASK >> f) & 1u) != 0 && (kSingle || fmt == f); };   // compile-time false for absent formats
   const uint32_t tb = is(F_Q4K) ? fmt_tile_bytes(F_Q4K) : is(F_Q6K) ? fmt_tile_bytes(F_Q6K) : is(F_Q5K) ? fmt_tile_bytes(F_Q5K)
                       : is(F_Q80) ? fmt_tile_bytes(F_Q80) : fmt_tile_bytes(F_Q40);
-  const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x7FFFu;
+  const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x3FFFu;
   const bool nrm = (geom >> 31) != 0;
+  constexpr bool from_attn = ATTN;   // the input vector is merged from the attention's split partials (geom bit 30, host-checked)
   const uint32_t S_nblk = geom2 & 0xFFFFu, Rg = geom2 >> 16;
   const uint32_t S_rpw = 16u * Rg * S_G;
   const uint32_t wg = bid - S_wgb;
@@ -507,10 +558,18 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
     auto run = [&](auto n_first) {
       constexpr int NF = decltype(n_first)::value;
       LGH_WSTAMP(2);
-      x_request();
+      if constexpr (from_attn) {
+        // tiles first (they do not depend on anything), then the partials: the merged k-slice is complete when the first
+        // tiles have landed (loads return in order)
 #pragma unroll
-      for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
-      x_finish(n_first);
+        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+        mvq_gather_attn(L.attn_ml, L.attn_acc, L.attn_splits, L.attn_g, L.attn_dshift, blk0, nblk_w, const_cast<uint8_t*>(xrec), lane);
+      } else {
+        x_request();
+#pragma unroll
+        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+        x_finish(n_first);
+      }
       LGH_WSTAMP(5);
       if constexpr (NF < kDepth) {   // that was everything
 #pragma unroll
@@ -572,11 +631,11 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   LGH_SPAN(1);
 }
 
-template <uint32_t MASK>
+template <uint32_t MASK, bool ATTN = false>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  mvq_body<MASK, false>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+  mvq_body<MASK, false, ATTN>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -676,12 +735,12 @@ size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
-template <uint32_t MASK>
+template <uint32_t MASK, bool ATTN = false>
 static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
                          uint32_t geom2, uint32_t red_off) {
   static bool attr_set[64] = {};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_kernel<MASK>), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mvq_kernel<MASK>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_kernel<MASK, ATTN>), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL((mvq_kernel<MASK, ATTN>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
   return hipGetLastError();
 }
 
@@ -701,9 +760,10 @@ uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp*
     mask |= 1u << f;
   }
   const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
-  if (S0.T > 255 || S0.G > 255 || S0.units > 0x7FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return 0;
+  if (S0.T > 255 || S0.G > 255 || S0.units > 0x3FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return 0;
+  if (L.attn_acc && (L.nseg != 1 || S0.npass != 1 || L.do_norm || L.attn_splits == 0 || L.attn_splits > kMergeMaxSplits)) return 0;
   g->wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
-  g->geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
+  g->geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u) | (L.attn_acc ? 1u << 30 : 0u);
   g->geom2 = S0.nblk | Rg << 16;
   g->red_floats = L.red_floats;
   g->lds_red_off = mvq_red_offset(threads / 64, S0.units);
@@ -718,6 +778,16 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
   size_t lds = 0;
   const uint32_t mask = mvq_pack(L, n_wg, threads, &g, &lds);
   const uint32_t wbpack = g.wbpack, geom = g.geom, geom2 = g.geom2, red_off = g.lds_red_off;
+  if (L.attn_acc) {   // the output projection fed from the attention's split partials: single-format instantiations
+    switch (mask) {
+      case 1u << F_Q4K: return mvq_go<(1u << F_Q4K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+      case 1u << F_Q6K: return mvq_go<(1u << F_Q6K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+      case 1u << F_Q5K: return mvq_go<(1u << F_Q5K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+      case 1u << F_Q80: return mvq_go<(1u << F_Q80), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+      case 1u << F_Q40: return mvq_go<(1u << F_Q40), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
+      default: return hipErrorInvalidValue;
+    }
+  }
 #define LGH_MVQ_CASE(M) case M: return mvq_go<M>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
   switch (mask) {   // single formats and the two mixes of the "_M" quantisations (fused QKV: V in Q6_K)
     LGH_MVQ_CASE(1u << F_Q4K); LGH_MVQ_CASE(1u << F_Q6K); LGH_MVQ_CASE(1u << F_Q5K); LGH_MVQ_CASE(1u << F_Q80); LGH_MVQ_CASE(1u << F_Q40);

@@ -49,7 +49,8 @@ struct PtAttn {
   uint32_t out_cnt;              // one counter per kv head: every split slot arrives once per token (s_max arrivals)
   uint32_t s_max;                // split slots per kv head (workgroups n_kv * s_max take part)
   uint32_t rows_per_split;       // splits in use = clamp(ceil(kv_len / rows_per_split), 1, s_max)
-  uint32_t pad[2];
+  uint32_t lds_off;              // LDS bytes in front of the attention's scratch (per-wave partial states)
+  uint32_t pad[1];
 };
 
 struct PtProgram {
@@ -63,7 +64,8 @@ struct PtProgram {
 
 // host side (decode_persistent.hip)
 struct PtHostOp { PtOp op; MvLaunch mv; PtAttn attn; uint32_t threads; uint64_t alg_bytes; };
-size_t ptok_lds_bytes(const PtHostOp* ops, size_t n, uint32_t head_dim, uint32_t group);
+// lays out LDS: x regions | two partial-sum buffers (alternating between ops) | attention scratch; patches the ops; returns the total
+size_t ptok_layout_lds(PtHostOp* ops, size_t n, uint32_t head_dim, uint32_t group);
 // format mask of the program's matrices (0: not runnable) and whether an instantiation for (mask, head_dim, group) exists
 uint32_t ptok_mask(const PtHostOp* ops, size_t n);
 bool ptok_supported(uint32_t mask, uint32_t head_dim, uint32_t group);

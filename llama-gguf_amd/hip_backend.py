@@ -44,7 +44,7 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
              "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>", "lgh::ptok_kernel")
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
-FLAG_NO_PERSISTENT = 8   # decode as one launch per op instead of the persistent token kernel (LGH_NO_PERSISTENT=1 sets it too)
+FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)
 FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
 
@@ -175,7 +175,7 @@ class HipGpuInference:
     # -- pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>  (gpu_only.rs:426)
     @classmethod
     def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
-                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0) -> "HipGpuInference":
+                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, attn_merge: int = 0) -> "HipGpuInference":
         """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
         `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
         L = load_library()
@@ -194,9 +194,10 @@ class HipGpuInference:
         d.layer_begin, d.layer_end = lb, le
         if os.environ.get("LGH_CHAIN_FFN", "") not in ("", "0"):
             flags |= FLAG_CHAIN_FFN
-        if os.environ.get("LGH_NO_PERSISTENT", "") not in ("", "0"):
-            flags |= FLAG_NO_PERSISTENT
-        d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16)   # attn_direct: 64-row units, 255 = never
+        if os.environ.get("LGH_PERSISTENT", "") not in ("", "0"):
+            flags |= FLAG_PERSISTENT
+        # attn_direct / attn_merge: 64-row units, 0 = tuned default, 255 = never
+        d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16) | ((attn_merge & 0xFF) << 24)
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
         try:

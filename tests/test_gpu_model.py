@@ -395,3 +395,33 @@ def test_unsupported_attention_shape_is_refused_at_create(pkg):
     with pytest.raises(pkg.BackendError) as ei:
         pkg.HipGpuInference.from_model(model, 16)
     assert ei.value.variant == "Unsupported"
+
+
+@pytest.mark.parametrize("name,mix", [("test-dense", "Q4_K_M"), ("test-dense-d128", "Q4_K_M"), ("test-dense", "Q8_0"), ("test-dense", "Q5_K_M")])
+def test_optional_decode_paths_follow_the_oracle(pkg, orc, name, mix):
+    """Two opt-in decode structures that are kept next to the default hipGraph of one launch per op: the persistent token
+    kernel (LGH_FLAG_PERSISTENT: one launch per token, data-flow hand-offs, attention inside) and the 8-split attention whose
+    partials the output projection merges itself (attn_merge).  Same tolerances as the default path; greedy tokens identical
+    to the default path's."""
+    cfg, ref, base = _pair(pkg, orc, name, mix, max_seq=160)
+    model = pkg.SynthModel(cfg, mix=mix)
+    engs = [pkg.HipGpuInference.from_model(model, 160, flags=pkg.hip_backend.FLAG_PERSISTENT),
+            pkg.HipGpuInference.from_model(model, 160, attn_merge=2)]
+    assert engs[0].stats()["graph_nodes"] == 0
+    toks = [(29 * i + 3) % cfg.vocab_size for i in range(90)]
+    worst = [0.0, 0.0]
+    for i, t in enumerate(toks):
+        want = ref.forward([t])
+        got = [e.forward(t) for e in engs]
+        base.prefill_token(t)
+        if i in (0, 1, 2, 30, 63, 64, 65, 89):
+            for k, g in enumerate(got):
+                worst[k] = max(worst[k], float(np.abs(g - want).max()))
+                assert np.abs(g - want).max() <= _tol(want), (k, i)
+    assert engs[0].stats()["graph_nodes"] <= 3          # embedding + the token kernel (+ arg-max)
+    want = base.decode_greedy(11, 24).tolist()
+    for e in engs:
+        assert e.decode_greedy(11, 24).tolist() == want
+    print(f"{name}/{mix}: persistent max|dlogit|={worst[0]:.3e}, merged attention max|dlogit|={worst[1]:.3e}")
+    for e in engs + [base]:
+        e.close()

@@ -13,7 +13,7 @@ ap.add_argument("--model", default="llama-3-8b"); ap.add_argument("--mix", defau
 a = ap.parse_args()
 pkg = graft.load_package()
 cfg = pkg.make_config(a.model, max_seq_len=a.kv + 64)
-eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=a.mix), a.kv + 64)
+eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=a.mix), a.kv + 64, flags=pkg.hip_backend.FLAG_PERSISTENT)
 for t in range(a.kv):
     eng.prefill_token(t % cfg.vocab_size)
 eng.decode_greedy(5, 8)
@@ -31,7 +31,9 @@ for k, nm in enumerate(names):
     beg = s[:, :, 0].min(axis=1, keepdims=True)
     def rel(i): return ((s[:, :, i] - beg) / 100.0)
     if nm == "attn":
-        print(f"{nm:8s} begin->end: wave-mean {rel(7).mean():6.2f} us  (max over waves {rel(7).max(axis=1).mean():6.2f})")
+        row = " ".join(f"{lbl}={rel(i).mean():5.2f}/{rel(i).max(axis=1).mean():5.2f}" for i, lbl in
+                       ((1, "polled"), (2, "bar"), (3, "rows"), (4, "wavemerge+bar"), (5, "stores"), (6, "drain"), (7, "end")))
+        print(f"{nm:8s} (mean/max over waves, us since op begin) {row}")
         continue
     row = " ".join(f"{lbl}={rel(i).mean():5.2f}/{rel(i).max(axis=1).mean():5.2f}" for i, lbl in
                    ((1, "waited"), (2, "x_in"), (3, "items"), (4, "bar1"), (5, "epi"), (6, "drain"), (7, "end")))

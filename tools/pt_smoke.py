@@ -8,8 +8,8 @@ def run(name, mix, n=12, **kw):
     ref = orc.Model(cfg.as_dict())
     for nm, t, ne, data in model.tensors(keep=True): ref.add_tensor(nm, t, ne, data)
     ref.finalize()
-    a = pkg.HipGpuInference.from_model(model, 96)
-    b = pkg.HipGpuInference.from_model(model, 96, flags=pkg.hip_backend.FLAG_NO_PERSISTENT)
+    a = pkg.HipGpuInference.from_model(model, 96, flags=pkg.hip_backend.FLAG_PERSISTENT)
+    b = pkg.HipGpuInference.from_model(model, 96)
     print(name, mix, 'graph nodes pt', a.stats()['graph_nodes'], flush=True)
     toks = [3, 17, 255, 9, 5]
     worst = 0
