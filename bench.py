@@ -113,6 +113,10 @@ def parse_args():
     ap.add_argument("--attn-merge", type=int, default=0, help="8-split attention merged by the output projection up to 64*n rows (0 = default, 255 = never)")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of the K-step region (SURVEY.md §8d: 1 warm-up + 3, mean and min)")
     ap.add_argument("--flags", type=int, default=0, help="extra LGH_FLAG_* bits for the engine context")
+    ap.add_argument("--inlib", action="store_true",
+                    help="N > 1 in ONE process: the in-library pipeline (lgh_pipeline_*: peer copies + events between the stages' streams) "
+                         "instead of one rank per GPU over RCCL")
+    ap.add_argument("--stages", type=int, default=0, help="with --inlib: stage count when it differs from --gpus (several stages on one GPU)")
     ap.add_argument("--fake-stage", action="store_true",
                     help="CPU rehearsal of the N>1 launcher and hop protocol: gloo + pipeline.FakeStage, no GPU, no engine (not a measurement)")
     return ap.parse_args()
@@ -417,6 +421,56 @@ def run_pipeline(args, pkg):
     dist.destroy_process_group()
 
 
+def run_inlib(args, pkg):
+    """The layer pipeline inside the library, one process: `--gpus` devices, `--stages` stage contexts (default one per device)."""
+    import torch
+    hb = pkg.hip_backend
+    n_dev = hb.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no HIP device visible (the engine has no CPU fallback)")
+    stages = args.stages or args.gpus
+    devices = [min(s * args.gpus // stages, n_dev - 1) for s in range(stages)]
+    W, K = args.warmup, args.steps
+    reps = max(args.reps, 1)
+    max_seq = max(512, args.prompt + W + reps * K + 16)
+    cfg = pkg.make_config(args.model, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=args.mix)
+    eng = pkg.HipPipeline.from_model(model, max_seq, stages, devices=devices, flags=args.flags)
+    prompt = prompt_tokens(args.prompt, cfg.vocab_size)
+    for t in prompt[:-1]:
+        eng.prefill_token(t)
+    eng.forward(prompt[-1])
+    tok = int(eng.decode_greedy(prompt[-1], W)[-1]) if W > 0 else prompt[-1]
+    kv0 = eng.position()
+    rep_s = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tok = int(eng.decode_greedy(tok, K)[-1])       # returns after every stage's stream has drained
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t0)
+    kv1 = eng.position()
+    elapsed = sum(rep_s) / len(rep_s)
+    tok_s = K / elapsed
+    step_bytes = model.step_alg_bytes(int(round((kv0 + 1 + kv0 + K) / 2)))
+    eng.close()
+    print(json.dumps({
+        "metric": f"decode tokens/sec {args.model} {args.mix}, {len(set(devices))} GPUs (in-library layer pipeline, {stages} stages); % of HBM roofline",
+        "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": len(set(devices)), "steps": K, "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": DTYPE_LABEL, "data": "synthetic",
+        "repetitions": {"n": len(rep_s), "ms_per_step": [round(1e3 * r / K, 4) for r in rep_s], "min_ms_per_step": round(1e3 * min(rep_s) / K, 4),
+                        "best_value": round(K / min(rep_s), 2)},
+        "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, kv_len {kv0 + 1}..{kv1}",
+                   "parallelism": f"pp{stages} in one process on devices {devices}: per token one f32[hidden] peer copy per stage boundary and "
+                                  f"the 4-byte token fed back device to device (hipMemcpyPeerAsync + events); no collective",
+                   "prompt_tokens": args.prompt},
+        "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
+                         "peak_GBps_one_gpu": HBM_PEAK_GBPS, "frac_of_one_gpu": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4)},
+        "roofline": None, "cpu_baseline": None,
+    }))
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` (N > 1) started WITHOUT a launcher: this parent — which has touched no GPU, loaded no HIP
     library and imported no torch — starts `python -m torch.distributed.run` with N ranks of this same script as a child
@@ -450,7 +504,7 @@ def self_launch(args) -> int:
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("LGH_BENCH_FORCE_PIPELINE"):
+    if args.gpus > 1 and "RANK" not in os.environ and not os.environ.get("LGH_BENCH_FORCE_PIPELINE") and not args.inlib:
         sys.exit(self_launch(args))
     # ONE JSON line on stdout, nothing else: native libraries write banners to fd 1 (RCCL prints its version block there
     # at communicator creation), so fd 1 is pointed at stderr for the whole run and the result goes to the saved descriptor.
@@ -464,7 +518,9 @@ def main():
     from importlib import import_module
     pkg.pipeline = import_module("llama_gguf_amd.pipeline")
     # LGH_BENCH_FORCE_PIPELINE=1: run the N>1 code path with however many ranks there are (a 1-rank rehearsal on a 1-GPU box)
-    if args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LGH_BENCH_FORCE_PIPELINE"):
+    if args.inlib:
+        run_inlib(args, pkg)
+    elif args.gpus > 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("LGH_BENCH_FORCE_PIPELINE"):
         run_pipeline(args, pkg)
     else:
         run_single(args, pkg)

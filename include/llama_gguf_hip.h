@@ -251,6 +251,30 @@ int lgh_stage_io_buffers(lgh_ctx* ctx, void** token_in, void** argmax_out);
 int lgh_stage_step(lgh_ctx* ctx, int mode);
 /* Last stage: the arg-max tokens logged at positions [pos0, pos0 + n) (one device-to-host copy, synchronises). */
 int lgh_stage_read_tokens(lgh_ctx* ctx, size_t pos0, size_t n, uint32_t* out);
+/* Last stage: the logits of the last lgh_stage_step(ctx, 1 or 2) (vocab_size f32; one device-to-host copy, synchronises). */
+int lgh_stage_read_logits(lgh_ctx* ctx, float* logits_out);
+
+/* ---- the layer pipeline inside the library: ONE process, n_stages stage contexts on the given devices (device_ids NULL:
+ * all on desc->device_id), contiguous near-equal layer ranges (earlier stages take the remainder).  Replaces
+ * PipelineExecutor::forward (src/distributed/pipeline.rs:50-96) + ShardServer::forward (src/distributed/shard.rs:377-445)
+ * for a host that links this library: per token and stage boundary one f32[hidden_size] peer copy over xGMI on the producing
+ * stage's stream and an event the consuming stage waits for; in lgh_pipeline_decode_greedy the arg-max token goes from the
+ * last stage's device word into the first stage's the same way — no host value crosses a stage boundary per token.  The
+ * entry points mirror the single-context ones (GpuInference, src/backend/mod.rs:283-296), so GpuModelWrapper drives a
+ * pipeline handle unchanged. ---- */
+typedef struct lgh_pipeline lgh_pipeline;
+int lgh_pipeline_create(const lgh_model_desc* desc, const int* device_ids, int n_stages, lgh_pipeline** out);
+int lgh_pipeline_upload_tensor(lgh_pipeline* p, const char* gguf_name, uint32_t ggml_type, const uint64_t ne[4],
+                               const void* host_bytes, size_t nbytes);
+int lgh_pipeline_finalize(lgh_pipeline* p);
+void lgh_pipeline_destroy(lgh_pipeline* p);
+int lgh_pipeline_forward(lgh_pipeline* p, uint32_t token_id, float* logits_out);      /* GpuInference::forward */
+int lgh_pipeline_prefill_token(lgh_pipeline* p, uint32_t token_id);                   /* GpuInference::prefill_token */
+int lgh_pipeline_decode_greedy(lgh_pipeline* p, uint32_t first_token, size_t n_steps, uint32_t* tokens_out);
+void lgh_pipeline_reset(lgh_pipeline* p);                                             /* GpuInference::reset */
+size_t lgh_pipeline_position(const lgh_pipeline* p);                                  /* GpuInference::position */
+int lgh_pipeline_stages(const lgh_pipeline* p);
+const char* lgh_pipeline_last_error(const lgh_pipeline* p);
 
 /* ---- per-op surface: the `Backend` trait ops on the path (src/backend/mod.rs:29-265), host tensors
  * in / host tensors out, for parity tests of each kernel against the CPU backend. ---- */

@@ -8,5 +8,5 @@ package is registered as ``llama_gguf_amd`` by ``__graft_entry__.load_package()`
   synth.py         synthetic random-init models (no model files exist in this environment)
 """
 from . import hip_backend, synth  # noqa: F401
-from .hip_backend import BackendError, GpuModelWrapper, HipBackend, HipGpuInference, InferenceContext  # noqa: F401
+from .hip_backend import BackendError, GpuModelWrapper, HipBackend, HipGpuInference, HipPipeline, InferenceContext  # noqa: F401
 from .synth import ModelConfig, SynthModel, make_config  # noqa: F401

@@ -1711,6 +1711,16 @@ int lgh_stage_step(lgh_ctx* c, int mode) {
   return step(c, mode);
 }
 
+int lgh_stage_read_logits(lgh_ctx* c, float* logits_out) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (!logits_out) return fail(c, LGH_INVALID_ARGUMENT, "logits_out is NULL");
+  if (!c->last) return fail(c, LGH_INVALID_ARGUMENT, "only the last stage holds logits");
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+  return check_chain(c);
+}
+
 int lgh_stage_read_tokens(lgh_ctx* c, size_t pos0, size_t n, uint32_t* out) {
   int rc = check_ready(c);
   if (rc) return rc;

@@ -31,7 +31,10 @@ ABI_SYMBOLS = (
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
     "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
-    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get",
+    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get", "lgh_stage_read_logits",
+    "lgh_pipeline_create", "lgh_pipeline_upload_tensor", "lgh_pipeline_finalize", "lgh_pipeline_destroy", "lgh_pipeline_forward",
+    "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_stages",
+    "lgh_pipeline_last_error",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc", "token")
@@ -143,6 +146,13 @@ def load_library() -> C.CDLL:
         "lgh_stage_io_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]), "lgh_stage_step": (C.c_int, [vp, C.c_int]),
         "lgh_stage_read_tokens": (C.c_int, [vp, sz, sz, vp]),
         "lgh_gguf_get": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GgufValue), C.c_char_p, sz]),
+        "lgh_stage_read_logits": (C.c_int, [vp, vp]),
+        "lgh_pipeline_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+        "lgh_pipeline_upload_tensor": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(C.c_uint64), vp, sz]),
+        "lgh_pipeline_finalize": (C.c_int, [vp]), "lgh_pipeline_destroy": (None, [vp]),
+        "lgh_pipeline_forward": (C.c_int, [vp, u32, vp]), "lgh_pipeline_prefill_token": (C.c_int, [vp, u32]),
+        "lgh_pipeline_decode_greedy": (C.c_int, [vp, u32, sz, vp]), "lgh_pipeline_reset": (None, [vp]),
+        "lgh_pipeline_position": (sz, [vp]), "lgh_pipeline_stages": (C.c_int, [vp]), "lgh_pipeline_last_error": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -346,6 +356,83 @@ class HipGpuInference:
     def close(self) -> None:
         if self._h:
             load_library().lgh_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipPipeline:
+    """The in-library layer pipeline behind the GpuInference surface (lgh_pipeline_*): one process, `n_stages` stage contexts
+    on `devices` (default: all on device 0), hidden vector and greedy token hopped device to device.  `GpuModelWrapper`
+    drives it like a single HipGpuInference."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        self.config = None
+        self.vocab_size = 0
+
+    @classmethod
+    def from_model(cls, model, max_seq_len: int, n_stages: int, devices: Optional[Sequence[int]] = None, flags: int = 0) -> "HipPipeline":
+        L = load_library()
+        self = cls()
+        cfg = model.config
+        d = ModelDesc()
+        d.struct_size = C.sizeof(ModelDesc)
+        for k in ("hidden_size", "intermediate_size", "num_layers", "num_heads", "num_kv_heads", "head_dim",
+                  "vocab_size", "num_experts", "num_experts_per_token", "expert_intermediate_size"):
+            setattr(d, k, int(getattr(cfg, k)))
+        d.max_seq_len = int(max_seq_len)
+        d.use_neox_rope = int(cfg.use_neox_rope)
+        d.norm_eps, d.rope_freq_base, d.rope_freq_scale = cfg.norm_eps, cfg.rope_freq_base, cfg.rope_freq_scale
+        d.device_id, d.flags = 0, flags
+        devs = (C.c_int * n_stages)(*devices) if devices is not None else None
+        _chk(L.lgh_pipeline_create(C.byref(d), devs, n_stages, C.byref(self._h)), "lgh_pipeline_create (is a HIP device visible?)")
+        self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
+        try:
+            for name, t, ne, data in model.tensors():
+                data = np.ascontiguousarray(data)
+                ne = list(ne)
+                ne4 = (C.c_uint64 * 4)(*(ne + [0] * (4 - len(ne))))
+                self._call(L.lgh_pipeline_upload_tensor(self._h, name.encode(), t, ne4, data.ctypes.data, data.nbytes))
+            self._call(L.lgh_pipeline_finalize(self._h))
+        except Exception:
+            self.close()
+            raise
+        return self
+
+    def _call(self, status: int) -> None:
+        if status != 0:
+            raise BackendError(status, load_library().lgh_pipeline_last_error(self._h).decode())
+
+    def forward(self, token_id: int) -> np.ndarray:
+        logits = np.empty(self.vocab_size, dtype=np.float32)
+        self._call(load_library().lgh_pipeline_forward(self._h, token_id, logits.ctypes.data))
+        return logits
+
+    def prefill_token(self, token_id: int) -> None:
+        self._call(load_library().lgh_pipeline_prefill_token(self._h, token_id))
+
+    def decode_greedy(self, first_token: int, n_steps: int) -> np.ndarray:
+        out = np.zeros(n_steps, dtype=np.uint32)
+        self._call(load_library().lgh_pipeline_decode_greedy(self._h, first_token, n_steps, out.ctypes.data))
+        return out
+
+    def reset(self) -> None:
+        load_library().lgh_pipeline_reset(self._h)
+
+    def position(self) -> int:
+        return load_library().lgh_pipeline_position(self._h)
+
+    def stages(self) -> int:
+        return load_library().lgh_pipeline_stages(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            load_library().lgh_pipeline_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -425,3 +425,35 @@ def test_optional_decode_paths_follow_the_oracle(pkg, orc, name, mix):
     print(f"{name}/{mix}: persistent max|dlogit|={worst[0]:.3e}, merged attention max|dlogit|={worst[1]:.3e}")
     for e in engs + [base]:
         e.close()
+
+
+@pytest.mark.parametrize("name,mix,stages", [("test-dense-d128", "Q4_K_M", 2), ("test-dense-d128", "Q4_K_M", 3), ("test-moe", "Q5_K_M", 2)])
+def test_in_library_pipeline_equals_single_context(pkg, orc, name, mix, stages):
+    """lgh_pipeline_*: `stages` stage contexts in ONE process (here all on one device: the peer copy degenerates to a
+    device-to-device copy), hidden vector and greedy token hopped on the device.  Logits and greedy tokens must equal the
+    single context's bit for bit (src/distributed/pipeline.rs:50-96 partitioning), and GpuModelWrapper drives the pipeline
+    handle unchanged."""
+    cfg = pkg.make_config(name, max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix=mix)
+    one = pkg.HipGpuInference.from_model(model, 64)
+    pipe = pkg.HipPipeline.from_model(model, 64, stages)
+    assert pipe.stages() == stages
+    try:
+        wrap, ctx = pkg.GpuModelWrapper(pipe), pkg.InferenceContext()
+        prompt = [3, 900 % cfg.vocab_size, 31, 7]
+        for t in prompt[:-1]:
+            one.prefill_token(t)
+        assert np.array_equal(wrap.forward(prompt, ctx), one.forward(prompt[-1]))
+        assert pipe.position() == one.position() == 4
+        assert pipe.decode_greedy(5, 24).tolist() == one.decode_greedy(5, 24).tolist()
+        assert np.array_equal(pipe.forward(9), one.forward(9))
+        pipe.reset()
+        one.reset()
+        assert pipe.position() == 0
+        assert np.array_equal(pipe.forward(2), one.forward(2))
+        with pytest.raises(pkg.BackendError) as ei:
+            pipe.forward(cfg.vocab_size)
+        assert ei.value.variant == "InvalidArgument"
+    finally:
+        one.close()
+        pipe.close()
