@@ -325,6 +325,63 @@ hipError_t attn_generic_launch(const float* q, const float* k, const float* v, f
   return hipGetLastError();
 }
 
+// Decode attention for ANY head_dim / query-heads-per-kv-head inside the engine (the templated kernels above cover
+// head_dim 64 / 128 with 1, 2, 4, 8 heads per kv head): one workgroup per query head, kv_len = *pos + 1 from the device,
+// scores in LDS (max_seq floats), the arithmetic of ops.rs:1479-1537 (dot per score, max, exp, sum, weights x 1/sum, V
+// accumulated in position order).  Slower than the split kernels, correct for every shape the reference's kernel takes
+// (kernels.rs:1395-1458).
+__global__ void __launch_bounds__(256) attn_decode_any_kernel(const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                              float* __restrict__ out, uint32_t per_kv, uint32_t max_seq, uint32_t d, float scale,
+                                                              const int* __restrict__ pos_ptr) {
+  extern __shared__ float sc[];
+  __shared__ float s_red[4];
+  const uint32_t head = blockIdx.x, kvh = head / per_kv, kv_len = (uint32_t)*pos_ptr + 1;
+  const float* qv = q + (size_t)head * d;
+  const float* kb = kc + (size_t)kvh * max_seq * d;
+  const float* vb = vc + (size_t)kvh * max_seq * d;
+  float m = -INFINITY;
+  for (uint32_t p = threadIdx.x; p < kv_len; p += 256) {
+    float dot = 0.0f;
+    for (uint32_t i = 0; i < d; i++) dot += qv[i] * kb[(size_t)p * d + i];
+    sc[p] = dot * scale;
+    m = fmaxf(m, sc[p]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float sum = 0.0f;
+  for (uint32_t p = threadIdx.x; p < kv_len; p += 256) {
+    const float e = expf(sc[p] - m);
+    sc[p] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+  for (uint32_t i = threadIdx.x; i < d; i += 256) {
+    float o = 0.0f;
+    for (uint32_t p = 0; p < kv_len; p++) o += (sc[p] * inv) * vb[(size_t)p * d + i];
+    out[(size_t)head * d + i] = o;
+  }
+}
+
+bool attn_shape_has_fast_kernel(uint32_t head_dim, uint32_t group) {
+  return (head_dim == 64 || head_dim == 128) && (group == 1 || group == 2 || group == 4 || group == 8);
+}
+
+hipError_t attn_decode_any_launch(const float* q, const float* kcache, const float* vcache, float* out, uint32_t n_heads, uint32_t n_kv,
+                                  uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || !pos || (size_t)max_seq * 4 > 150 * 1024) return hipErrorInvalidValue;
+  static bool attr_set[64] = {};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_decode_any_kernel), 152 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL(attn_decode_any_kernel, dim3(n_heads), dim3(256), (size_t)max_seq * 4, st, q, kcache, vcache, out, n_heads / n_kv, max_seq,
+                     head_dim, scale, pos);
+  return hipGetLastError();
+}
+
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || head_dim % 16 || head_dim > 128 || n_splits > 32) return hipErrorInvalidValue;

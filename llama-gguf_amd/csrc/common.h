@@ -213,6 +213,9 @@ hipError_t attn_launch(const float* q, const float* kcache, const float* vcache,
                        uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
 hipError_t attn_direct_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
                               uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st);
+bool attn_shape_has_fast_kernel(uint32_t head_dim, uint32_t group);
+hipError_t attn_decode_any_launch(const float* q, const float* kcache, const float* vcache, float* out, uint32_t n_heads, uint32_t n_kv,
+                                  uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, hipStream_t st);
 hipError_t attn_generic_launch(const float* q, const float* k, const float* v, float* out, uint32_t n_heads, uint32_t n_kv, uint32_t seq_len,
                                uint32_t kv_len, uint32_t kv_rows, uint32_t d, float scale, hipStream_t st);
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,

@@ -487,7 +487,14 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
   const bool merge = c->attn_merge && !c->attn_direct && mfma_type(Lw.wo.type);
-  if (c->attn_direct) {
+  if (!attn_shape_has_fast_kernel(d.head_dim, d.num_heads / d.num_kv_heads)) {
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_decode_any_launch(c->q, Lw.kcache, Lw.vcache, c->attn_out, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
+                                         c->state + ST_POS, c->stream);
+         })))
+      return rc;
+    xq_stale(c, c->attn_out);
+  } else if (c->attn_direct) {
     XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_direct_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
@@ -575,37 +582,46 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
          return moe_router_launch(c->hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, d.num_experts, topk, c->moe_sel, c->moe_w, c->stream);
        })))
     return rc;
-  if (!fused_type(Lw.gate_exps.type) || Lw.gate_exps.type != Lw.up_exps.type || !fused_type(Lw.down_exps.type) || topk > 2)
-    return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 2");
-  {
-    SegSpec sp;
-    sp.npass = (int)(2 * topk);
-    for (uint32_t s = 0; s < topk; s++) {
-      sp.W[2 * s] = &Lw.gate_exps; sp.W[2 * s + 1] = &Lw.up_exps;
-      sp.x[2 * s] = sp.x[2 * s + 1] = c->hidden;
-      sp.sel[2 * s] = sp.sel[2 * s + 1] = c->moe_sel + s;
+  if (!fused_type(Lw.gate_exps.type) || Lw.gate_exps.type != Lw.up_exps.type || !fused_type(Lw.down_exps.type) || topk > 8)
+    return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 8");
+  // The selected experts run two at a time (a launch carries up to four passes: gate and up of two experts).  Every group
+  // reads the SAME normalised h, so the running sum lives in a scratch vector until the last group writes the residual
+  // stream: tmp = (w0 e0 + w1 e1) + h; tmp = (w2 e2 + w3 e3) + tmp; ...; h = (...) + tmp   (moe.rs:363-368 adds the weighted
+  // expert outputs in selection order and then the residual; same terms, grouped by two).
+  for (uint32_t g0 = 0; g0 < topk; g0 += 2) {
+    const uint32_t ng = std::min(2u, topk - g0);
+    const bool first_g = g0 == 0, last_g = g0 + ng >= topk;
+    {
+      SegSpec sp;
+      sp.npass = (int)(2 * ng);
+      for (uint32_t s = 0; s < ng; s++) {
+        sp.W[2 * s] = &Lw.gate_exps; sp.W[2 * s + 1] = &Lw.up_exps;
+        sp.x[2 * s] = sp.x[2 * s + 1] = c->hidden;
+        sp.sel[2 * s] = sp.sel[2 * s + 1] = c->moe_sel + g0 + s;
+      }
+      sp.epi = EPI_MOE_SWIGLU;
+      sp.out = c->act; sp.out2 = c->act2;
+      sp.xq_next = mfma_type(Lw.down_exps.type) ? 1 : 0;
+      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
     }
-    sp.epi = EPI_MOE_SWIGLU;
-    sp.out = c->act; sp.out2 = c->act2;
-    sp.xq_next = mfma_type(Lw.down_exps.type) ? 1 : 0;
-    if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
-  }
-  {
-    SegSpec sp;
-    sp.npass = (int)topk;
-    for (uint32_t s = 0; s < topk; s++) {
-      sp.W[s] = &Lw.down_exps;
-      sp.x[s] = s == 0 ? c->act : c->act2;
-      sp.sel[s] = c->moe_sel + s;
+    {
+      SegSpec sp;
+      sp.npass = (int)ng;
+      for (uint32_t s = 0; s < ng; s++) {
+        sp.W[s] = &Lw.down_exps;
+        sp.x[s] = s == 0 ? c->act : c->act2;
+        sp.sel[s] = c->moe_sel + g0 + s;
+      }
+      sp.epi = EPI_MOE_DOWN;
+      sp.out = last_g ? c->hidden : c->xnorm;
+      sp.resid = first_g ? c->hidden : c->xnorm;
+      sp.moe_w = c->moe_w + g0;
+      sp.xq_next = last_g && next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
+      if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
     }
-    sp.epi = EPI_MOE_DOWN;
-    sp.out = c->hidden; sp.resid = c->hidden; sp.moe_w = c->moe_w;
-    sp.xq_next = next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
-    if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
   }
   return LGH_OK;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // The persistent token kernel's program (decode_persistent.hip): every mat-vec and attention op of a decode step of this
@@ -1150,13 +1166,15 @@ int engine_shape_check(const lgh_model_desc& d, std::string& why) {
     return LGH_INVALID_ARGUMENT;
   }
   const uint32_t g = d.num_heads / d.num_kv_heads;
-  if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) {
-    why = "decode attention is built for head_dim 64 or 128 and 1, 2, 4 or 8 query heads per kv head; this model has head_dim " +
-          std::to_string(d.head_dim) + " and " + std::to_string(g) + " query heads per kv head";
+  // head_dim 64 / 128 with 1, 2, 4, 8 query heads per kv head take the split attention kernels; every other shape takes the
+  // one-workgroup-per-head kernel (attention.hip: attn_decode_any_kernel), whose scores live in LDS
+  if (!attn_shape_has_fast_kernel(d.head_dim, g) && (size_t)d.max_seq_len * 4 > 150 * 1024) {
+    why = "head_dim " + std::to_string(d.head_dim) + " with " + std::to_string(g) + " query heads per kv head runs the generic attention "
+          "kernel, which holds max_seq_len scores in LDS: max_seq_len must be <= 38400 for it (got " + std::to_string(d.max_seq_len) + ")";
     return LGH_UNSUPPORTED;
   }
-  if (d.num_experts && (d.num_experts_per_token == 0 || d.num_experts_per_token > 2 || d.num_experts > 64)) {
-    why = "MoE layers are built for top-1 / top-2 routing over at most 64 experts; this model routes top-" +
+  if (d.num_experts && (d.num_experts_per_token == 0 || d.num_experts_per_token > 8 || d.num_experts_per_token > d.num_experts || d.num_experts > 64)) {
+    why = "MoE layers route top-1 .. top-8 over at most 64 experts; this model routes top-" +
           std::to_string(d.num_experts_per_token) + " over " + std::to_string(d.num_experts);
     return LGH_UNSUPPORTED;
   }

@@ -387,13 +387,42 @@ def test_per_expert_upload_matches_stacks_and_a_missing_expert_fails_finalize(pk
     assert ei.value.variant == "InitializationFailed" and "blk.1.ffn_up.{3}.weight" in str(ei.value)
 
 
-def test_unsupported_attention_shape_is_refused_at_create(pkg):
-    """A shape the kernels are not built for (7 query heads per kv head, Qwen2-7B's 28 / 4) is refused by lgh_create with
-    Unsupported before anything is uploaded, not by a launch error in finalize."""
-    cfg = pkg.make_config("test-dense", max_seq_len=16, num_heads=14, num_kv_heads=2, hidden_size=896)
-    model = pkg.SynthModel(cfg, mix="Q8_0")
+def test_generic_attention_shapes_and_top_k_follow_the_oracle(pkg, orc):
+    """Shapes outside the templated attention kernels (the reference's kernel takes any head_dim / group size,
+    kernels.rs:1395-1458) run the one-workgroup-per-head kernel; MoE layers with more than two selected experts run them two
+    at a time (moe.rs:321-413).  Qwen2-7B's 7 query heads per kv head, head_dim 96, top-3 and top-4 routing."""
+    cases = [("test-dense", "Q8_0", dict(num_heads=14, num_kv_heads=2, head_dim=64, hidden_size=896)),           # G = 7, k % 256 != 0
+             ("test-dense", "Q4_K_M", dict(num_heads=8, num_kv_heads=4, head_dim=96, hidden_size=768, intermediate_size=1536)),   # head_dim 96
+             ("test-dense", "Q4_K_M", dict(num_heads=6, num_kv_heads=2, head_dim=128, hidden_size=768, intermediate_size=1536)),  # G = 3
+             ("test-moe", "Q4_K_M", dict(num_experts=6, num_experts_per_token=3)),
+             ("test-moe", "Q5_K_M", dict(num_experts=8, num_experts_per_token=4))]
+    for name, mix, kw in cases:
+        cfg, ref, eng = _pair(pkg, orc, name, mix, max_seq=48, **kw)
+        toks = [(31 * i + 2) % cfg.vocab_size for i in range(20)]
+        worst = 0.0
+        for i, t in enumerate(toks):
+            got, want = eng.forward(t), ref.forward([t])
+            worst = max(worst, float(np.abs(got - want).max()))
+            assert np.abs(got - want).max() <= _tol(want), (name, kw, i)
+        pos = eng.position()
+        dev = eng.decode_greedy(3, 10).tolist()
+        eng.kv_truncate(pos)
+        host, tok = [], 3
+        for _ in range(10):
+            tok = orc.argmax_last(eng.forward(tok))
+            host.append(tok)
+        assert dev == host
+        print(f"{name}/{mix} {kw}: max|dlogit|={worst:.3e}")
+        eng.close()
+        ref.close()
+
+
+def test_generic_attention_refuses_contexts_that_do_not_fit_lds(pkg):
+    """The generic attention kernel keeps max_seq_len scores in LDS: a longer context is refused by lgh_create with
+    Unsupported and a message naming the shape (not by a launch error in finalize)."""
+    cfg = pkg.make_config("test-dense", max_seq_len=50000, num_heads=14, num_kv_heads=2, hidden_size=896)
     with pytest.raises(pkg.BackendError) as ei:
-        pkg.HipGpuInference.from_model(model, 16)
+        pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix="Q8_0"), 50000)
     assert ei.value.variant == "Unsupported"
 
 
