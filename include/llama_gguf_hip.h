@@ -91,6 +91,8 @@ enum {
   LGH_FLAG_PERSISTENT = 1u << 3,     /* decode with the persistent token kernel (one launch per token, data-flow hand-offs between ops;
                                         csrc/decode_persistent.hip) instead of the hipGraph of one launch per op.  Correct and tested, but
                                         MEASURED SLOWER on MI355X (2.6 vs 1.6 ms per Llama-3-8B token), so it is opt-in */
+  LGH_FLAG_KV_INT8 = 1u << 4,        /* KV cache in the reference's int8 format (QuantizedKVCache / KVCacheFormat::Int8, src/model/kv_quantized.rs;
+                                        `--kv-cache-type`): int8 rows + one f32 scale per (kv head, position), a quarter of the f32 cache */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
   LGH_FLAG_ATTN_DIRECT_SHIFT = 16,   /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
                                         per kv head, no split + combine pair); 0 = the tuned default, 255 = never */

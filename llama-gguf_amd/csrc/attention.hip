@@ -164,6 +164,179 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// int8 KV cache (LGH_FLAG_KV_INT8): the reference's QuantizedKVCache with KVCacheFormat::Int8
+// (src/model/kv_quantized.rs:143-300, 385-410).  Per layer K and V are int8 [kv_head][max_seq][D] plus one f32 scale per
+// (kv_head, position): scale = max|x| / 127 (1 for an all-zero row), q = round(x / scale) clamped, and attention reads
+// back scale * q.  The QKV launch leaves the current token's rows as f32 in a staging vector; every attention workgroup of
+// a kv head quantizes that row itself (D values, the same bits everywhere), split 0 also stores it into the cache, and the
+// row takes part in the softmax through its dequantized values — exactly what a later token will read.
+// Same split / online-softmax structure as attn_partial_kernel; a row is D bytes (one dword per lane).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 unpack_i8x4(uint32_t w, float scale) {
+  f32x4 r;
+  r.x = (float)(int)(int8_t)(w & 0xFFu) * scale;
+  r.y = (float)(int)(int8_t)((w >> 8) & 0xFFu) * scale;
+  r.z = (float)(int)(int8_t)((w >> 16) & 0xFFu) * scale;
+  r.w = (float)(int)(int8_t)(w >> 24) * scale;
+  return r;
+}
+
+// quantizes the f32 row held 4 elements per lane by the LPR lanes of a row group; returns the packed int8 word and the scale
+template <int LPR>
+__device__ __forceinline__ uint32_t quantize_row_i8(f32x4 x, float& scale) {
+  float amax = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+  amax = fmaxf(amax, dpp_f<0xB1>(amax));
+  amax = fmaxf(amax, dpp_f<0x4E>(amax));
+  amax = fmaxf(amax, dpp_f<0x141>(amax));
+  amax = fmaxf(amax, dpp_f<0x140>(amax));
+  if (LPR == 32) amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+  scale = amax > 1e-10f ? amax / 127.0f : 1.0f;
+  auto qz = [&](float v) -> uint32_t {
+    float r = roundf(v / scale);                           // f32::round: halves away from zero
+    r = r < -128.0f ? -128.0f : (r > 127.0f ? 127.0f : r);
+    return (uint32_t)(int)r & 0xFFu;
+  };
+  return qz(x.x) | qz(x.y) << 8 | qz(x.z) << 16 | qz(x.w) << 24;
+}
+
+template <int D, int G, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_partial_q8_kernel(const float* __restrict__ q, int8_t* __restrict__ k8, int8_t* __restrict__ v8,
+                                                                  float* __restrict__ kscale, float* __restrict__ vscale,
+                                                                  const float* __restrict__ k_new, const float* __restrict__ v_new,
+                                                                  uint32_t max_seq, float scale, const int* pos_ptr, uint32_t n_splits,
+                                                                  float* __restrict__ part_ml, float* __restrict__ part_acc) {
+  constexpr int LPR = D / 4, RPW = 64 / LPR;
+  __shared__ float s_ml[NW][G][2];
+  __shared__ float s_acc[NW][G][D];
+  const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sub = lane / LPR, li = lane % LPR;
+  uint32_t pw;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
+  const uint32_t pos = pw;   // rows [0, pos) come from the cache, row `pos` from the staging vectors
+  f32x4 qv[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) qv[g] = *reinterpret_cast<const f32x4*>(q + ((size_t)kvh * G + g) * D + li * 4);
+  float m[G], l[G];
+  f32x4 acc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) { m[g] = kNegBig; l[g] = 0.0f; acc[g] = (f32x4)(0.0f); }
+  auto step = [&](bool valid, f32x4 k4, f32x4 v4) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      float s = qv[g].x * k4.x;
+      s = __builtin_fmaf(qv[g].y, k4.y, s);
+      s = __builtin_fmaf(qv[g].z, k4.z, s);
+      s = __builtin_fmaf(qv[g].w, k4.w, s);
+      s += dpp_f<0xB1>(s);
+      s += dpp_f<0x4E>(s);
+      s += dpp_f<0x141>(s);
+      s += dpp_f<0x140>(s);
+      if (LPR == 32) s += __shfl_xor(s, 16, 64);
+      s *= scale;
+      const float mn = valid ? fmaxf(m[g], s) : m[g];
+      const float a = __expf(m[g] - mn);
+      const float pe = valid ? __expf(s - mn) : 0.0f;
+      l[g] = __builtin_fmaf(l[g], a, pe);
+      acc[g] = acc[g] * a + v4 * pe;
+      m[g] = mn;
+    }
+  };
+  const size_t hrow = (size_t)kvh * max_seq;
+  const uint32_t stride = n_splits * NW * RPW;
+  constexpr int kAhead = 4;
+  for (uint32_t base = (sp * NW + wave) * RPW; base < pos; base += kAhead * stride) {
+    uint32_t kk[kAhead], vv[kAhead];
+    float ks[kAhead], vs[kAhead];
+#pragma unroll
+    for (int j = 0; j < kAhead; j++) {
+      const uint32_t p = base + j * stride + sub, r = p < pos ? p : pos - 1;
+      kk[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(k8 + (hrow + r) * D + li * 4));
+      vv[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(v8 + (hrow + r) * D + li * 4));
+      ks[j] = kscale[hrow + r];
+      vs[j] = vscale[hrow + r];
+    }
+#pragma unroll
+    for (int j = 0; j < kAhead; j++)
+      if (base + j * stride < pos) step(base + j * stride + sub < pos, unpack_i8x4(kk[j], ks[j]), unpack_i8x4(vv[j], vs[j]));
+  }
+  if (wave == 0) {   // the current token's row: quantized here (every split the same bits), stored by split 0
+    const f32x4 kx = *reinterpret_cast<const f32x4*>(k_new + (size_t)kvh * D + li * 4);
+    const f32x4 vx = *reinterpret_cast<const f32x4*>(v_new + (size_t)kvh * D + li * 4);
+    float ksc, vsc;
+    const uint32_t kq = quantize_row_i8<LPR>(kx, ksc), vq = quantize_row_i8<LPR>(vx, vsc);
+    if (sp == 0) {
+      if (sub == 0) {
+        *reinterpret_cast<uint32_t*>(k8 + (hrow + pos) * D + li * 4) = kq;
+        *reinterpret_cast<uint32_t*>(v8 + (hrow + pos) * D + li * 4) = vq;
+        if (li == 0) { kscale[hrow + pos] = ksc; vscale[hrow + pos] = vsc; }
+      }
+      step(sub == 0, unpack_i8x4(kq, ksc), unpack_i8x4(vq, vsc));
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float om = __shfl_xor(m[g], off, 64), ol = __shfl_xor(l[g], off, 64);
+      f32x4 oa;
+      oa.x = __shfl_xor(acc[g].x, off, 64); oa.y = __shfl_xor(acc[g].y, off, 64);
+      oa.z = __shfl_xor(acc[g].z, off, 64); oa.w = __shfl_xor(acc[g].w, off, 64);
+      const float mn = fmaxf(m[g], om);
+      const float a = expf(m[g] - mn), b = expf(om - mn);
+      l[g] = l[g] * a + ol * b;
+      acc[g] = acc[g] * a + oa * b;
+      m[g] = mn;
+    }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (li == 0) { s_ml[wave][g][0] = m[g]; s_ml[wave][g][1] = l[g]; }
+      *reinterpret_cast<f32x4*>(&s_acc[wave][g][li * 4]) = acc[g];
+    }
+  }
+  __syncthreads();
+  const size_t pbase = ((size_t)kvh * n_splits + sp) * G;
+  for (uint32_t e = threadIdx.x; e < (uint32_t)(G * D); e += NW * 64) {
+    const uint32_t g = e / D, dim = e % D;
+    float mn = s_ml[0][g][0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mn = fmaxf(mn, s_ml[w][g][0]);
+    float lsum = 0.0f, a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float f = expf(s_ml[w][g][0] - mn);
+      lsum += s_ml[w][g][1] * f;
+      a += s_acc[w][g][dim] * f;
+    }
+    part_acc[(pbase + g) * D + dim] = a;
+    if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
+  }
+}
+
+template <int D, int G>
+static hipError_t attn_q8_go(const float* q, int8_t* k8, int8_t* v8, float* ks, float* vs, const float* k_new, const float* v_new, uint32_t n_kv,
+                             uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
+  hipLaunchKernelGGL((attn_partial_q8_kernel<D, G, 4>), dim3(n_kv * n_splits), dim3(256), 0, st, q, k8, v8, ks, vs, k_new, v_new, max_seq, scale, pos,
+                     n_splits, part_ml, part_acc);
+  return hipGetLastError();
+}
+
+hipError_t attn_q8_launch(const float* q, int8_t* k8, int8_t* v8, float* kscale, float* vscale, const float* k_new, const float* v_new,
+                          uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
+                          float* part_ml, float* part_acc, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || !pos) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_ATTN_CASE(DD, GG) \
+  if (head_dim == DD && g == GG) return attn_q8_go<DD, GG>(q, k8, v8, kscale, vscale, k_new, v_new, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st);
+  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
+  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
+#undef LGH_ATTN_CASE
+  return hipErrorInvalidValue;
+}
+
 // out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}.  Lane s of the first wave owns split s
 // (all loads of a phase are independent and in flight together: the kernel is two memory round trips long).
 __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,

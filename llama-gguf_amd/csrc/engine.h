@@ -19,6 +19,9 @@ struct LayerW {
   float* bq = nullptr; float* bk = nullptr; float* bv = nullptr; float* bo = nullptr;
   float* kcache = nullptr;
   float* vcache = nullptr;
+  // LGH_FLAG_KV_INT8: int8 rows [kv_head][max_seq][head_dim] + one f32 scale per (kv_head, position) instead of the f32 caches
+  int8_t *k8 = nullptr, *v8 = nullptr;
+  float *kscale = nullptr, *vscale = nullptr;
   bool moe() const { return router != nullptr; }
 };
 

@@ -461,11 +461,14 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   int rc;
   // ---- attention: norm -> q,k,v -> rope -> cache write (layers.rs:438-600)
   const bool fused_qkv = fused_type(Lw.wq.type) && fused_type(Lw.wk.type) && fused_type(Lw.wv.type) && !d.use_neox_rope;
+  const bool kv8 = (d.flags & LGH_FLAG_KV_INT8) != 0;
+  float* const k_new = c->kv_tmp;                                           // int8 cache: the current token's rotated K row ...
+  float* const v_new = c->kv_tmp + (size_t)d.num_kv_heads * d.head_dim;     // ... and V row, f32, quantized by the attention launch
   if (fused_qkv) {
     SegSpec sp[3];
     sp[0].W[0] = &Lw.wq; sp[0].x[0] = c->hidden; sp[0].epi = EPI_ROPE_Q; sp[0].out = c->q; sp[0].bias = Lw.bq;
-    sp[1].W[0] = &Lw.wk; sp[1].x[0] = c->hidden; sp[1].epi = EPI_ROPE_K; sp[1].out = Lw.kcache; sp[1].bias = Lw.bk;
-    sp[2].W[0] = &Lw.wv; sp[2].x[0] = c->hidden; sp[2].epi = EPI_V_CACHE; sp[2].out = Lw.vcache; sp[2].bias = Lw.bv;
+    sp[1].W[0] = &Lw.wk; sp[1].x[0] = c->hidden; sp[1].epi = kv8 ? EPI_ROPE_Q : EPI_ROPE_K; sp[1].out = kv8 ? k_new : Lw.kcache; sp[1].bias = Lw.bk;
+    sp[2].W[0] = &Lw.wv; sp[2].x[0] = c->hidden; sp[2].epi = kv8 ? EPI_STORE : EPI_V_CACHE; sp[2].out = kv8 ? v_new : Lw.vcache; sp[2].bias = Lw.bv;
     if ((rc = launch_mv(c, LGH_K_QKV, sp, 3, Lw.attn_norm, H))) return rc;
   } else {
     float* kt = c->kv_tmp;
@@ -478,16 +481,31 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
            return rope_launch(c->q, kt, d.num_heads, d.num_kv_heads, d.head_dim, c->state + ST_POS, c->rope_cs, (int)d.use_neox_rope, c->stream);
          })))
       return rc;
-    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] {
+    if (!kv8 && (rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] {
            return kv_store_launch(kt, vt, Lw.kcache, Lw.vcache, d.num_kv_heads, d.head_dim, d.max_seq_len, c->state + ST_POS, c->stream);
          })))
       return rc;
   }
   // ---- attention_cached (ops.rs:1479-1537)
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
-  const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
+  const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * (kv8 ? d.head_dim + 4 : d.head_dim * 4);
   const bool merge = c->attn_merge && !c->attn_direct && mfma_type(Lw.wo.type);
-  if (!attn_shape_has_fast_kernel(d.head_dim, d.num_heads / d.num_kv_heads)) {
+  if (kv8) {
+    // int8 rows + scales (kv_quantized.rs); the launch also quantizes and stores the current token's rows
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_q8_launch(c->q, Lw.k8, Lw.v8, Lw.kscale, Lw.vscale, k_new, v_new, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
+                                 scale, c->state + ST_POS, c->n_splits, c->part_ml, c->part_acc, c->stream);
+         })))
+      return rc;
+    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
+    if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
+           return attn_combine_launch(c->part_ml, c->part_acc, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out, qa ? qa->xq : nullptr,
+                                      c->stream);
+         })))
+      return rc;
+    if (qa) { qa->fresh = true; qa->tag = nullptr; }
+    else xq_stale(c, c->attn_out);
+  } else if (!attn_shape_has_fast_kernel(d.head_dim, d.num_heads / d.num_kv_heads)) {
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_decode_any_launch(c->q, Lw.kcache, Lw.vcache, c->attn_out, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
                                          c->state + ST_POS, c->stream);
@@ -639,7 +657,7 @@ static int pt_build(lgh_ctx* c, int mode) {
   const lgh_model_desc& d = c->d;
   const uint32_t H = d.hidden_size, D = d.head_dim, NH = d.num_heads, NKV = d.num_kv_heads, G = NH / NKV;
   auto no = [&](const std::string& why) { R.why = why; return LGH_OK; };
-  if (!(d.flags & LGH_FLAG_PERSISTENT) || (d.flags & LGH_FLAG_CHAIN_FFN)) return no("not requested (LGH_FLAG_PERSISTENT)");
+  if (!(d.flags & LGH_FLAG_PERSISTENT) || (d.flags & (LGH_FLAG_CHAIN_FFN | LGH_FLAG_KV_INT8))) return no("not requested (LGH_FLAG_PERSISTENT)");
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < kNumCU) return no("device has fewer than 256 CUs");
   if (H % 256 || (NH * D) % 256 || d.use_neox_rope || c->l0 >= c->l1) return no("shape");
@@ -996,7 +1014,7 @@ static int set_token(lgh_ctx* c, uint32_t token) {
 // ------------------------------------------------------------------------------------------------
 static bool pf_eligible(const lgh_ctx* c) {
   const lgh_model_desc& d = c->d;
-  if (d.flags & LGH_FLAG_EXACT_PREFILL) return false;
+  if (d.flags & (LGH_FLAG_EXACT_PREFILL | LGH_FLAG_KV_INT8)) return false;   // (the batched path writes f32 K/V rows)
   const uint32_t QD = d.num_heads * d.head_dim, KD = d.num_kv_heads * d.head_dim, g = d.num_heads / d.num_kv_heads;
   if (d.hidden_size % 256 || d.hidden_size > 2048u * kPfSsqChunks || QD % 256 || KD % 16) return false;
   if ((d.head_dim != 64 && d.head_dim != 128) || (g != 1 && g != 2 && g != 4 && g != 8)) return false;
@@ -1173,6 +1191,10 @@ int engine_shape_check(const lgh_model_desc& d, std::string& why) {
           "kernel, which holds max_seq_len scores in LDS: max_seq_len must be <= 38400 for it (got " + std::to_string(d.max_seq_len) + ")";
     return LGH_UNSUPPORTED;
   }
+  if ((d.flags & LGH_FLAG_KV_INT8) && (!attn_shape_has_fast_kernel(d.head_dim, g) || (d.flags & (LGH_FLAG_PERSISTENT | LGH_FLAG_CHAIN_FFN)))) {
+    why = "the int8 KV cache runs on the split attention kernels (head_dim 64 / 128; 1, 2, 4 or 8 query heads per kv head) of the default decode path";
+    return LGH_UNSUPPORTED;
+  }
   if (d.num_experts && (d.num_experts_per_token == 0 || d.num_experts_per_token > 8 || d.num_experts_per_token > d.num_experts || d.num_experts > 64)) {
     why = "MoE layers route top-1 .. top-8 over at most 64 experts; this model routes top-" +
           std::to_string(d.num_experts_per_token) + " over " + std::to_string(d.num_experts);
@@ -1227,6 +1249,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   const uint32_t msel = (d.flags >> LGH_FLAG_ATTN_MERGE_SHIFT) & 0xFFu;
   c->merge_attn_max_kv = msel == 255 ? 0 : msel ? msel * 64 : kMergeAttnDefaultKv;
   if (c->merge_attn_max_kv && c->merge_attn_max_kv <= c->direct_attn_max_kv) c->merge_attn_max_kv = 0;
+  if (d.flags & LGH_FLAG_KV_INT8) c->direct_attn_max_kv = c->merge_attn_max_kv = 0;   // the int8 cache has one attention structure: splits + combine
   if ((d.num_heads * d.head_dim) % 256 || d.head_dim % 64 || (d.flags & LGH_FLAG_CHAIN_FFN)) c->merge_attn_max_kv = 0;
   if (const char* e = std::getenv("LGH_MERGE_SPLITS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) c->merge_splits = (uint32_t)v; }
   *out = c;
@@ -1372,6 +1395,20 @@ int lgh_finalize(lgh_ctx* c) {
       }
     } else if (!L.gate.present() || !L.up.present() || !L.down.present()) {
       return fail(c, LGH_INITIALIZATION_FAILED, "missing FFN weights of " + p);
+    }
+    if (d.flags & LGH_FLAG_KV_INT8) {
+      // QuantizedKVCache::new with KVCacheFormat::Int8 (kv_quantized.rs:57-102): int8 rows + a scale per (kv head, position)
+      const size_t n_rows = (size_t)d.num_kv_heads * d.max_seq_len;
+      for (int8_t** p8 : {&L.k8, &L.v8}) {
+        if ((rc = dev_alloc(c, (void**)p8, kv_elems))) return rc;
+        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*p8, 0, kv_elems, c->stream));
+      }
+      for (float** ps : {&L.kscale, &L.vscale}) {
+        if ((rc = dev_alloc(c, (void**)ps, n_rows * 4))) return rc;
+        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*ps, 0, n_rows * 4, c->stream));
+      }
+      c->stats.kv_bytes += 2 * (kv_elems + n_rows * 4);
+      continue;
     }
     // per-layer K/V [kv_heads, max_seq, head_dim] f32 (gpu_only.rs:555-572)
     if ((rc = dev_alloc(c, (void**)&L.kcache, kv_elems * 4))) return rc;
@@ -1570,13 +1607,23 @@ int lgh_kv_shift_left(lgh_ctx* c, size_t amount) {
     // tensor goes through a scratch buffer: two strided device-to-device copies instead of the host's memmove.
     const size_t new_len = c->pos - amount, row = (size_t)d.head_dim * 4;
     if (!c->kv_shift_tmp && (rc = dev_alloc(c, (void**)&c->kv_shift_tmp, (size_t)d.num_kv_heads * d.max_seq_len * row))) return rc;
-    for (uint32_t li = c->l0; li < c->l1; li++)
-      for (float* cache : {c->layers[li].kcache, c->layers[li].vcache}) {
-        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(c->kv_shift_tmp, new_len * row, cache + amount * d.head_dim, (size_t)d.max_seq_len * row,
-                                                          new_len * row, d.num_kv_heads, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(cache, (size_t)d.max_seq_len * row, c->kv_shift_tmp, new_len * row, new_len * row,
-                                                          d.num_kv_heads, hipMemcpyDeviceToDevice, c->stream));
+    // (base, bytes per position): the f32 caches, or the int8 rows and their scales (QuantizedKVCache::shift_left, kv_quantized.rs:330-372)
+    auto shift = [&](void* base, size_t rb) -> int {
+      uint8_t* b = (uint8_t*)base;
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(c->kv_shift_tmp, new_len * rb, b + amount * rb, (size_t)d.max_seq_len * rb, new_len * rb,
+                                                        d.num_kv_heads, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy2DAsync(b, (size_t)d.max_seq_len * rb, c->kv_shift_tmp, new_len * rb, new_len * rb, d.num_kv_heads,
+                                                        hipMemcpyDeviceToDevice, c->stream));
+      return LGH_OK;
+    };
+    for (uint32_t li = c->l0; li < c->l1; li++) {
+      LayerW& L = c->layers[li];
+      if (d.flags & LGH_FLAG_KV_INT8) {
+        if ((rc = shift(L.k8, d.head_dim)) || (rc = shift(L.v8, d.head_dim)) || (rc = shift(L.kscale, 4)) || (rc = shift(L.vscale, 4))) return rc;
+      } else if ((rc = shift(L.kcache, row)) || (rc = shift(L.vcache, row))) {
+        return rc;
       }
+    }
     c->pos = new_len;
   }
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), (int)c->pos, 1, c->stream));
@@ -1629,8 +1676,9 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
       if (L.moe()) b += (uint64_t)d.num_experts_per_token * (L.gate_exps.bytes + L.up_exps.bytes + L.down_exps.bytes) + (uint64_t)d.num_experts * d.hidden_size * 4;
       else b += L.gate.bytes + L.up.bytes + L.down.bytes;
       b += (uint64_t)2 * d.hidden_size * 4;                                       // norm weights
-      b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;          // KV read (kv_len = pos+1)
-      b += (uint64_t)2 * d.num_kv_heads * d.head_dim * 4;                         // KV write
+      const uint64_t kv_row = (d.flags & LGH_FLAG_KV_INT8) ? d.head_dim + 4 : (uint64_t)d.head_dim * 4;   // int8 row + its scale
+      b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * kv_row;                  // KV read (kv_len = pos+1)
+      b += (uint64_t)2 * d.num_kv_heads * kv_row;                                 // KV write
     }
     if (c->last) b += c->output.bytes + (uint64_t)d.hidden_size * 4 + (uint64_t)d.vocab_size * 4;
   }

@@ -48,6 +48,7 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)
+FLAG_KV_INT8 = 16   # KV cache in the reference's int8 format (kv_quantized.rs: int8 rows + one scale per head and position)
 FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
 

@@ -64,6 +64,7 @@ struct orc_model {
   LinearRef output;
   std::vector<float> embd_f32;  // dequantized table (kept unless faithful mode re-does it per call)
   std::vector<std::vector<float>> k_cache, v_cache;  // per layer [kv_heads][max_seq][head_dim]
+  bool kv_int8 = false;                               // rows go through the reference's int8 KV format on their way into the cache
   std::vector<float> last_hidden;
   size_t position = 0;
   bool finalized = false;
@@ -131,6 +132,17 @@ int attention_forward(orc_model* m, size_t li, const float* x, size_t pos, float
   float* kc = m->k_cache[li].data();
   float* vc = m->v_cache[li].data();
   size_t ms = c.max_seq_len;
+  if (m->kv_int8) {
+    // QuantizedKVCache::write_kv + read_*_range with KVCacheFormat::Int8 (src/model/kv_quantized.rs:143-300): every head's row
+    // of every position is stored as int8 with one scale; what attention later reads back is scale * q
+    std::vector<int8_t> q8(d);
+    for (size_t h = 0; h < nkv; h++)
+      for (float* row : {k.data() + h * d, v.data() + h * d}) {
+        float sc = 1.0f;
+        orc_kv_quantize_int8(row, d, q8.data(), &sc);
+        orc_kv_dequantize_int8(q8.data(), sc, d, row);
+      }
+  }
   for (size_t h = 0; h < nkv; h++) {  // 577-600
     std::memcpy(kc + h * ms * d + pos * d, k.data() + h * d, d * 4);
     std::memcpy(vc + h * ms * d + pos * d, v.data() + h * d, d * 4);
@@ -298,6 +310,26 @@ int orc_model_finalize(orc_model* m) {
 
 void orc_model_reset(orc_model* m) { m->position = 0; }  // KVCache::reset (model/mod.rs:110-117): O(1)
 size_t orc_model_position(const orc_model* m) { return m->position; }
+
+void orc_model_set_kv_int8(orc_model* m, int on) { m->kv_int8 = on != 0; }
+
+// quantize_int8 / dequantize_int8 (src/model/kv_quantized.rs:385-410): symmetric, scale = max|x| / 127 (1 when the row is
+// all ~zero), q = round(x / scale) (f32::round: half away from zero) clamped to [-128, 127]
+void orc_kv_quantize_int8(const float* x, size_t n, int8_t* q, float* scale) {
+  float max_abs = 0.0f;
+  for (size_t i = 0; i < n; i++) max_abs = std::fmax(max_abs, std::fabs(x[i]));
+  const float sc = max_abs > 1e-10f ? max_abs / 127.0f : 1.0f;
+  for (size_t i = 0; i < n; i++) {
+    float r = std::round(x[i] / sc);
+    r = r < -128.0f ? -128.0f : (r > 127.0f ? 127.0f : r);
+    q[i] = (int8_t)r;
+  }
+  *scale = sc;
+}
+
+void orc_kv_dequantize_int8(const int8_t* q, float scale, size_t n, float* out) {
+  for (size_t i = 0; i < n; i++) out[i] = (float)q[i] * scale;
+}
 
 void orc_model_kv_truncate(orc_model* m, size_t new_len) {  // KVCache::truncate (model/mod.rs:130-134)
   if (new_len < m->position) m->position = new_len;

@@ -123,6 +123,11 @@ size_t orc_model_position(const orc_model* m);
 /* KVCache::truncate / shift_left (model/mod.rs:130-172); the position follows the cache (engine.rs:1407-1408) */
 void orc_model_kv_truncate(orc_model* m, size_t new_len);
 void orc_model_kv_shift_left(orc_model* m, size_t amount);
+/* the reference's int8 KV format (src/model/kv_quantized.rs:385-410, KVCacheFormat::Int8): one scale per head row */
+void orc_kv_quantize_int8(const float* x, size_t n, int8_t* q, float* scale);
+void orc_kv_dequantize_int8(const int8_t* q, float scale, size_t n, float* out);
+/* on: K/V rows pass through that format on their way into the cache (QuantizedKVCache::write_kv / read_k_range) */
+void orc_model_set_kv_int8(orc_model* m, int on);
 /* debug taps: hidden state after the last forward's final layer (pre-norm) */
 int orc_model_last_hidden(const orc_model* m, float* out);
 

@@ -71,6 +71,8 @@ def lib() -> C.CDLL:
         "orc_matmul": (None, [vp, vp, vp, sz, sz, sz]), "orc_matvec": (None, [vp, vp, vp, sz, sz]),
         "orc_attention": (None, [vp, vp, vp, vp, sz, sz, sz, sz, sz, C.c_float]),
         "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]), "orc_sum_f32": (C.c_float, [vp, sz]),
+        "orc_kv_quantize_int8": (None, [vp, sz, vp, vp]), "orc_kv_dequantize_int8": (None, [vp, C.c_float, sz, vp]),
+        "orc_model_set_kv_int8": (None, [vp, C.c_int]),
         "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
         "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),
@@ -266,6 +268,22 @@ def silu_mul(gate, up) -> np.ndarray:
     return g
 
 
+def kv_quantize_int8(x):
+    """quantize_int8 (kv_quantized.rs:385-405): (int8 values, scale)."""
+    x = _f32(x)
+    q = np.zeros(x.size, dtype=np.int8)
+    sc = C.c_float(0.0)
+    lib().orc_kv_quantize_int8(_p(x), x.size, _p(q), C.byref(sc))
+    return q, float(sc.value)
+
+
+def kv_dequantize_int8(q, scale: float) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.int8)
+    out = np.zeros(q.size, dtype=np.float32)
+    lib().orc_kv_dequantize_int8(_p(q), C.c_float(scale), q.size, _p(out))
+    return out
+
+
 def argmax_last(v) -> int:
     v = _f32(v)
     return int(lib().orc_argmax_last(_p(v), v.size))
@@ -293,6 +311,10 @@ class Model:
         self._keep = []
         self.vocab_size = cfg["vocab_size"]
         self.hidden_size = cfg["hidden_size"]
+
+    def set_kv_int8(self, on: bool = True) -> None:
+        """K/V rows go through the reference's int8 KV format (kv_quantized.rs) on their way into the cache."""
+        lib().orc_model_set_kv_int8(self._h, int(on))
 
     def add_tensor(self, name: str, t: int, ne, data: np.ndarray) -> None:
         data = np.ascontiguousarray(data)

@@ -486,3 +486,64 @@ def test_in_library_pipeline_equals_single_context(pkg, orc, name, mix, stages):
     finally:
         one.close()
         pipe.close()
+
+
+@pytest.mark.parametrize("name,mix,n_tok", [("test-dense", "Q4_K_M", 70), ("test-dense-d128", "Q4_K_M", 70), ("test-moe", "Q5_K_M", 40),
+                                            ("test-dense", "Q8_0", 4000)])
+def test_int8_kv_cache_follows_the_reference_format(pkg, orc, name, mix, n_tok):
+    """LGH_FLAG_KV_INT8: the reference's QuantizedKVCache / KVCacheFormat::Int8 (src/model/kv_quantized.rs:143-300, 385-410) on
+    the device — int8 rows + one scale per (kv head, position), quantized as the reference does (scale = max|x| / 127, round half
+    away from zero) and read back as scale * q.  Against the oracle with the same format switched on, context 1 ... 4000;
+    the cache is a quarter of the f32 one; shift_left / truncate move rows and scales together (:330-380)."""
+    max_seq = n_tok + 24
+    cfg = pkg.make_config(name, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=mix)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    ref.set_kv_int8(True)
+    eng = pkg.HipGpuInference.from_model(model, max_seq, flags=pkg.hip_backend.FLAG_KV_INT8)
+    f32 = pkg.HipGpuInference.from_model(model, max_seq)
+    assert eng.stats()["kv_bytes"] * 3 < f32.stats()["kv_bytes"]
+    f32.close()
+    try:
+        toks = [(41 * i + 7) % cfg.vocab_size for i in range(n_tok)]
+        check = set(range(8)) | {n_tok // 2, n_tok - 2, n_tok - 1} | set(range(60, 68))
+        worst = 0.0
+        if n_tok > 500:                                   # long context: the bulk goes in as a prompt on both sides
+            bulk = toks[:n_tok - 6]
+            for t in bulk:
+                eng.prefill_token(t)
+            ref.forward(bulk[:-1])
+            want = ref.forward(bulk[-1:])                 # (logits of the last prompt token on the oracle only)
+            toks = toks[n_tok - 6:]
+            check = set(range(6))
+        for i, t in enumerate(toks):
+            got, want = eng.forward(t), ref.forward([t])
+            if i in check:
+                worst = max(worst, float(np.abs(got - want).max()))
+                assert np.abs(got - want).max() <= _tol(want), (i, float(np.abs(got - want).max()))
+        print(f"{name}/{mix} int8 KV, {eng.position()} rows: max|dlogit|={worst:.3e}")
+        if n_tok <= 500:
+            for e in (eng, ref):
+                e.kv_shift_left(11)
+            assert eng.position() == ref.position
+            for t in (5, 6, 7):
+                got, want = eng.forward(t), ref.forward([t])
+                assert np.abs(got - want).max() <= _tol(want)
+            eng.kv_truncate(20)
+            ref.kv_truncate(20)
+            got, want = eng.forward(9), ref.forward([9])
+            assert np.abs(got - want).max() <= _tol(want)
+            pos = eng.position()
+            dev = eng.decode_greedy(3, 8).tolist()
+            eng.kv_truncate(pos)
+            host, tok = [], 3
+            for _ in range(8):
+                tok = orc.argmax_last(eng.forward(tok))
+                host.append(tok)
+            assert dev == host
+    finally:
+        eng.close()
+        ref.close()

@@ -255,3 +255,28 @@ def test_backend_trait_attention_kats(orc):
     full = orc.attention(qq, kk, vv, 0.35)
     cached = orc.attention_cached(qq[:, 2, :], kk, vv, 0.35, 5)
     assert np.allclose(full[:, 2, :], cached, atol=1e-6)
+
+
+def test_int8_kv_cache_kats(orc):
+    """The reference's int8 KV format (src/model/kv_quantized.rs): test_int8_roundtrip (:547-560), the Int8 leg of
+    test_quantized_kv_cache_basic (:612-665), test_shift_left's constant rows (:688-727: a row of equal values survives exactly)."""
+    data = np.arange(128, dtype=np.float32) * np.float32(0.1) - np.float32(6.4)
+    q, sc = orc.kv_quantize_int8(data)
+    assert abs(sc - 6.4 / 127.0) < 1e-7 and q[0] == -127 and q.min() >= -128 and q.max() <= 127
+    dec = orc.kv_dequantize_int8(q, sc)
+    rel = np.where(np.abs(data) > 1e-6, np.abs(data - dec) / np.maximum(np.abs(data), 1e-30), np.abs(data - dec))
+    assert rel.max() < 0.02
+    k = np.arange(4 * 64, dtype=np.float32) * np.float32(0.01) - np.float32(1.0)      # head 0 = the first 64 values
+    v = np.arange(4 * 64, dtype=np.float32) * np.float32(0.02) - np.float32(0.5)
+    for row in (k[:64], v[:64]):
+        q, sc = orc.kv_quantize_int8(row)
+        dec = orc.kv_dequantize_int8(q, sc)
+        rel = np.where(np.abs(row) > 1e-6, np.abs(row - dec) / np.maximum(np.abs(row), 1e-30), np.abs(row - dec))
+        assert rel.max() < 0.15
+    for pos in range(5):
+        q, sc = orc.kv_quantize_int8(np.full(4, float(pos), np.float32))
+        assert np.abs(orc.kv_dequantize_int8(q, sc) - pos).max() < 0.01
+    q, sc = orc.kv_quantize_int8(np.zeros(8, np.float32))       # an all-zero row: scale 1, values 0
+    assert sc == 1.0 and not q.any()
+    q, sc = orc.kv_quantize_int8(np.array([0.5, -1.5, 2.5, -2.5], np.float32) * np.float32(2.5 / 127 * 127 / 2.5))
+    assert list(q) == [25, -76, 127, -127]                       # f32::round: halves away from zero (25.4 -> 25, -76.2 -> -76)
