@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 R=$(pwd)
 
-timeout -k 10 600 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1
 rc=$?; tail -2 "$OUT/pytest_gpu.log"; [ $rc -ne 0 ] && { echo "pytest rc=$rc"; exit $rc; }
 
 timeout -k 10 300 python bench.py --steps "$STEPS" --warmup 16 > "$OUT/bench.json" 2> "$OUT/bench.err"

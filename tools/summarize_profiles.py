@@ -66,6 +66,16 @@ def main():
         for r in rows:
             w.writerow([r[0], r[1], f"{r[2]:.1f}", r[3], f"{r[4]:.1f}", f"{r[5]:.0f}"])
 
+    # which commit the PMC table was collected at: bench.py shows it next to roofline.traffic (a stale table is then visible)
+    import datetime
+    import subprocess
+    try:
+        commit = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], capture_output=True, text=True, check=True).stdout.strip()
+    except Exception:
+        commit = None
+    (dst / f"{tag}_meta.json").write_text(json.dumps({"commit": commit, "collected": datetime.date.today().isoformat(),
+                                                       "command": "tools/gpu_measure.sh " + tag}) + "\n")
+
     rl = bench["roofline"]
     kname = rl["kernel"]
     if rl.get("traffic") is None:   # the bench line ran before this session's PMC table existed: fill it from the same session
