@@ -112,16 +112,19 @@ enum {
 };
 
 /* kernel SYMBOLS reported by lgh_get_stats (profiling mode): what `rocprofv3 --kernel-trace --stats` groups by.
- * LGH_SYM_MV_* are the instantiations of lgh::mv_kernel<MASK, MAXT> (the fused dequant mat-vec). */
+ * LGH_SYM_MV_* are the instantiations of lgh::mv_kernel<MASK, MAXT> (the VALU dequant mat-vec, csrc/matvec.hip; MASK bits:
+ * Q4_K 1, Q5_K 2, Q6_K 4, Q8_0 8, Q4_0 16; MAXT = the instantiation's thread cap).  LGH_SYM_MVQ_* are the instantiations of
+ * lgh::mvq_kernel<MASK, ATTN> (the int8 matrix-core mat-vec; ATTN = true only for the output projection fed from attention partials, csrc/matvec_mfma.hip; ITS mask bits: Q4_K 1, Q6_K 2, Q5_K 4, Q8_0 8,
+ * Q4_0 16). */
 enum {
-  LGH_SYM_MV_Q4K = 0,      /* lgh::mv_kernel<1u, 1024>  : every launch whose matrices are all Q4_K */
-  LGH_SYM_MV_Q80 = 1,      /* lgh::mv_kernel<8u, 1024> */
-  LGH_SYM_MV_Q40 = 2,      /* lgh::mv_kernel<16u, 1024> */
-  LGH_SYM_MV_Q5K = 3,      /* lgh::mv_kernel<2u, 512> */
-  LGH_SYM_MV_Q6K = 4,      /* lgh::mv_kernel<4u, 512> */
-  LGH_SYM_MV_Q4K_Q6K = 5,  /* lgh::mv_kernel<5u, 512>   : mixed-type QKV launches */
-  LGH_SYM_MV_Q5K_Q6K = 6,  /* lgh::mv_kernel<6u, 512> */
-  LGH_SYM_MV_ALL = 7,      /* lgh::mv_kernel<31u, 512> */
+  LGH_SYM_MV_Q4K = 0,      /* lgh::mv_kernel<1u, 1024>  : every matrix of the launch Q4_K */
+  LGH_SYM_MV_Q80 = 1,      /* lgh::mv_kernel<8u, 1024>  : Q8_0 */
+  LGH_SYM_MV_Q40 = 2,      /* lgh::mv_kernel<16u, 1024> : Q4_0 */
+  LGH_SYM_MV_Q5K = 3,      /* lgh::mv_kernel<2u, 768>   : Q5_K */
+  LGH_SYM_MV_Q6K = 4,      /* lgh::mv_kernel<4u, 512>   : Q6_K */
+  LGH_SYM_MV_Q4K_Q6K = 5,  /* lgh::mv_kernel<5u, 512>   : Q4_K + Q6_K in one launch (fused QKV of Q4_K_M) */
+  LGH_SYM_MV_Q5K_Q6K = 6,  /* lgh::mv_kernel<6u, 512>   : Q5_K + Q6_K */
+  LGH_SYM_MV_ALL = 7,      /* lgh::mv_kernel<31u, 512>  : any other mix */
   LGH_SYM_F32_MATVEC = 8,  /* lgh::f32_matvec_kernel */
   LGH_SYM_ATTN = 9,        /* lgh::attn_partial_kernel<D, G> */
   LGH_SYM_ATTN_COMBINE = 10,
@@ -129,11 +132,11 @@ enum {
   LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
   LGH_SYM_ROUTER = 13,
   LGH_SYM_OTHER = 14,
-  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1u> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
-  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<2u> : ... every matrix Q6_K */
-  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
-  LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u> / <6u> : Q5_K (and Q5_K + Q6_K) */
-  LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u> / <16u> : Q8_0 / Q4_0 */
+  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1u, false> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
+  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<2u, false> : ... every matrix Q6_K */
+  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u, false> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
+  LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u, false> / <6u, false> : Q5_K (and Q5_K + Q6_K) */
+  LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u, false> / <16u, false> : Q8_0 / Q4_0 */
   LGH_SYM_PTOK = 20,       /* lgh::ptok_kernel<MASK, D, G> : the persistent token kernel (decode_persistent.hip) */
   LGH_SYM_COUNT = 24
 };

@@ -42,9 +42,10 @@ K_COUNT = 16
 SYM_COUNT = 24
 # kernel symbols as rocprofv3 prints them (LGH_SYM_* order)
 SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_kernel<16u, 1024>",
-             "lgh::mv_kernel<2u, 512>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
+             "lgh::mv_kernel<2u, 768>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
-             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>", "lgh::mvq_kernel<8u>", "lgh::ptok_kernel")
+             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u, false>", "lgh::mvq_kernel<2u, false>", "lgh::mvq_kernel<3u, false>", "lgh::mvq_kernel<4u, false>",
+             "lgh::mvq_kernel<8u, false>", "lgh::ptok_kernel")
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)

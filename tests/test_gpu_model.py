@@ -178,7 +178,8 @@ def test_profiling_stats(pkg, orc):
     eng.set_profiling(False)
     st = eng.stats()
     k = st["kernels"]
-    # a QKV launch splits in two when V is Q6_K (VALU kernel) while Q and K are Q4_K (matrix-core kernel)
+    # one fused QKV launch per layer when its three matrices share a kernel family (here: all on the matrix cores, Q4_K + Q6_K
+    # in the mixed instantiation); two when they do not (a family per launch)
     assert cfg.num_layers <= k["qkv"]["launches"] <= 2 * cfg.num_layers and k["gate_up"]["launches"] == cfg.num_layers
     assert k["output"]["launches"] == 1 and all(v["time_us"] > 0 for v in k.values())
     model = pkg.SynthModel(cfg, mix="Q4_K_M")
