@@ -91,6 +91,17 @@ enum {
   LGH_FLAG_PERSISTENT = 1u << 3,     /* decode with the persistent token kernel (one launch per token, data-flow hand-offs between ops;
                                         csrc/decode_persistent.hip) instead of the hipGraph of one launch per op.  Correct and tested, but
                                         MEASURED SLOWER on MI355X (2.6 vs 1.6 ms per Llama-3-8B token), so it is opt-in */
+  LGH_FLAG_OVERLAP = 1u << 5,        /* dense layers whose matrices are in the matrix-core tile layouts run wo | gate-up | down | next QKV as
+                                        flag-ordered launches on TWO streams of the token graph: each is dispatched while its producer still runs,
+                                        puts its first weight tiles in flight and waits for hand-off counters instead of a kernel boundary
+                                        (csrc/handoff.h).  Same arithmetic, identical results; MEASURED SLOWER (541 vs 612 tokens/s on Llama-3-8B:
+                                        the graph's cross-stream edges and the write-through hand-off cost more than the boundaries) */
+  LGH_FLAG_FLOW_FFN = 1u << 6,       /* dense layers: wo | gate-up | down as ONE launch whose workgroups are split between the three ops and
+                                        ordered by the same counters (no kernel boundary, no grid barrier; mvq_flow_kernel).  Identical results;
+                                        measured 595 vs 612 tokens/s, opt-in */
+  LGH_FLAG_ATTN_FUSED = 1u << 7,     /* decode attention without the combine launch: every split stores its partial state write-through and
+                                        counts itself in; the split that arrives last merges them (identical results).  Measured 594 vs 607
+                                        tokens/s: the atomic round trip in every workgroup's tail costs more than the launch it saves; opt-in */
   LGH_FLAG_KV_INT8 = 1u << 4,        /* KV cache in the reference's int8 format (QuantizedKVCache / KVCacheFormat::Int8, src/model/kv_quantized.rs;
                                         `--kv-cache-type`): int8 rows + one f32 scale per (kv head, position), a quarter of the f32 cache */
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
@@ -161,6 +172,9 @@ typedef struct lgh_stats {
    * profiled token — the fixed cost every k_time_us / sym_time_us sample carries on top of the kernel itself */
   double event_bracket_us;
   uint64_t event_bracket_samples;
+  /* producer -> consumer launch pairs of one decode step that run side by side on two streams, ordered by hand-off
+   * counters instead of a kernel boundary (LGH_FLAG_OVERLAP / LGH_FLAG_FLOW_FFN; 0 otherwise and where no pair of launches fits on a CU) */
+  uint64_t overlapped_edges;
 } lgh_stats;
 
 /* ---- lifecycle: replaces GpuOnlyInference::from_model (src/backend/cuda/gpu_only.rs:426-726) ---- */

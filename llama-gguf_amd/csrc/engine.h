@@ -104,8 +104,24 @@ struct lgh_ctx {
   std::vector<void*> allocs;  // everything hipMalloc'ed by this context
   std::vector<lgh::XqBuf> xqs;
   std::vector<lgh::ChainSlot> chains;          // [graph mode][layer]
+  unsigned* attn_arrive = nullptr;             // arrival counters of the split attention that merges itself (16 words per kv head)
+  bool attn_fuse = false;
+  std::vector<lgh::ChainSlot> flows;           // [graph mode][layer]: flow launches (wo | gate-up | down in one launch, hand-off counters)
+  bool flow_mode = false;
   std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
   unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
+  // flag-ordered graphs (handoff.h): two consecutive mat-vec launches of a layer run side by side on two streams, ordered by
+  // hand-off counters instead of a kernel boundary, so that the second one's weight tiles are in flight while the first finishes
+  bool flag_mode = false;                      // the context's graphs are captured that way
+  bool flagging = false;                       // ... and one is being captured right now
+  unsigned* flag_sync = nullptr;               // error word + counters
+  std::vector<uint32_t> flag_edges;            // per owned layer: overlapped edges (1: wo->gate-up, 2: gate-up->down, 4: down->next QKV)
+  std::vector<uint32_t> flag_cnt;              // per owned layer: first counter of wo's / gate-up's / down's output records (3 per layer)
+  hipStream_t stream2 = nullptr;               // the other stream of a flag-ordered capture
+  std::vector<hipEvent_t> flag_events;         // fork / join markers of the capture
+  size_t flag_ev_next = 0;
+  hipStream_t flag_origin = nullptr;           // the stream the token being enqueued started on
+  uint32_t flag_qkv_wait = lgh::kFlagNone;     // counters the next fused QKV launch waits for (the previous layer's down projection)
   lgh::PfScratch pf;
   lgh::PtProg pt[lgh::MODE_COUNT];             // persistent token kernel, per graph mode
   float* pt_part = nullptr;                    // attention split partials of the persistent kernel
@@ -141,6 +157,8 @@ struct SegSpec {
   const float* attn_ml = nullptr;
   const float* attn_acc = nullptr;
   uint32_t attn_splits = 0;
+  // flag-ordered launch (MvLaunch::flag_*): first counters of the input's / the output's XQ records
+  uint32_t flag_wait_first = lgh::kFlagNone, flag_sig_first = lgh::kFlagNone;
 };
 
 int fail(lgh_ctx* c, int status, const std::string& msg);

@@ -15,6 +15,7 @@
 //                                                            arg-max back on device
 //   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
 #include "engine.h"
+#include "handoff.h"
 #include "prefill.h"
 #include "xq.h"
 
@@ -256,6 +257,7 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
   L.dbg_slot = g_launch_seq++ & 63u;
+  L.flag_wait_first = L.flag_sig_first = kFlagNone;
   wg = 0; threads = 0; alg = 0;
   uint32_t launch_rows = 0;
   uint32_t wave_cap = 16;
@@ -309,6 +311,11 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
         if (norm_w) { L.ssq_part = q->ssq; L.n_ssq_part = k / 16; }
       }
       alg += W.bytes;
+    }
+    if (mfma && c->flagging && (sp.flag_wait_first != kFlagNone || sp.flag_sig_first != kFlagNone)) {
+      L.flag_sync = c->flag_sync;
+      L.flag_epoch = c->state + ST_EPOCH;
+      if (s == 0) { L.flag_wait_first = sp.flag_wait_first; L.flag_sig_first = sp.flag_sig_first; }
     }
     S.out = sp.out; S.out2 = sp.out2; S.resid = sp.resid; S.bias = sp.bias; S.moe_w = sp.moe_w;
     {  // XQ image of the output for the next consumer, where this epilogue can write one
@@ -368,7 +375,7 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
 // enqueue, uploaded once — during a stream capture the upload is deferred until the capture has ended.
 // ------------------------------------------------------------------------------------------------
 static int launch_ffn_chain(lgh_ctx* c, int mode, uint32_t li, const SegSpec* specs, const float* const* norm_ws, const uint32_t* ks,
-                            const int* clss, int nops) {
+                            const int* clss, int nops, bool flow = false) {
   MvLaunch Ls[kChainMaxOps];
   uint32_t wgs[kChainMaxOps], ths[kChainMaxOps];
   uint64_t alg = 0;
@@ -378,9 +385,10 @@ static int launch_ffn_chain(lgh_ctx* c, int mode, uint32_t li, const SegSpec* sp
     if (rc) return rc;
     alg += a;
   }
-  ChainSlot& slot = c->chains[(size_t)mode * c->d.num_layers + li];
+  ChainSlot& slot = (flow ? c->flows : c->chains)[(size_t)mode * c->d.num_layers + li];
   if (!slot.prepared) {
-    if (mvq_chain_prepare(Ls, wgs, ths, nops, &slot.host) != hipSuccess) return fail(c, LGH_UNSUPPORTED, "FFN chain: unsupported geometry");
+    if ((flow ? mvq_flow_prepare(Ls, wgs, ths, nops, &slot.host) : mvq_chain_prepare(Ls, wgs, ths, nops, &slot.host)) != hipSuccess)
+      return fail(c, LGH_UNSUPPORTED, "FFN chain: unsupported geometry");
     slot.prepared = true;
     slot.uploaded = false;
   }
@@ -398,8 +406,9 @@ static int launch_ffn_chain(lgh_ctx* c, int mode, uint32_t li, const SegSpec* sp
   const MvLaunch* dev_ops = reinterpret_cast<const MvLaunch*>(slot.dev);
   const MvChainOp* dev_geo = reinterpret_cast<const MvChainOp*>(slot.dev + sizeof(MvLaunch) * kChainMaxOps);
   (void)clss;
-  return run_k(c, LGH_K_GATEUP, slot.host.mask == 1u ? LGH_SYM_MVQ_Q4K : LGH_SYM_MVQ_MIXED, alg,
-               [&] { return mvq_chain_launch(slot.host, dev_ops, dev_geo, c->chain_sync, c->stream); });
+  return run_k(c, LGH_K_GATEUP, slot.host.mask == 1u ? LGH_SYM_MVQ_Q4K : LGH_SYM_MVQ_MIXED, alg, [&] {
+    return flow ? mvq_flow_launch(slot.host, dev_ops, dev_geo, c->stream) : mvq_chain_launch(slot.host, dev_ops, dev_geo, c->chain_sync, c->stream);
+  });
 }
 
 // Segments are independent (disjoint outputs), so a launch whose matrices live in different kernel families
@@ -450,6 +459,20 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
 }
 
 // ------------------------------------------------------------------------------------------------
+// flag-ordered capture (handoff.h): cross-stream edges of the graph being captured
+// ------------------------------------------------------------------------------------------------
+static hipStream_t flag_other(lgh_ctx* c, hipStream_t s) { return s == c->stream2 ? c->flag_origin : c->stream2; }
+
+// everything enqueued on `from` so far precedes whatever is enqueued on `to` from now on
+static int flag_edge(lgh_ctx* c, hipStream_t from, hipStream_t to) {
+  if (c->flag_ev_next >= c->flag_events.size()) return fail(c, LGH_OPERATION_FAILED, "flag-ordered capture: out of events");
+  hipEvent_t e = c->flag_events[c->flag_ev_next++];
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipEventRecord(e, from));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamWaitEvent(to, e, 0));
+  return LGH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // one transformer layer (TransformerLayer::forward serial-residual branch, layers.rs:1187-1244)
 // ------------------------------------------------------------------------------------------------
 // `next_nw` / `next_mfma`: the norm weights and kernel family of whatever consumes this layer's output (the next layer's
@@ -469,6 +492,9 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     sp[0].W[0] = &Lw.wq; sp[0].x[0] = c->hidden; sp[0].epi = EPI_ROPE_Q; sp[0].out = c->q; sp[0].bias = Lw.bq;
     sp[1].W[0] = &Lw.wk; sp[1].x[0] = c->hidden; sp[1].epi = kv8 ? EPI_ROPE_Q : EPI_ROPE_K; sp[1].out = kv8 ? k_new : Lw.kcache; sp[1].bias = Lw.bk;
     sp[2].W[0] = &Lw.wv; sp[2].x[0] = c->hidden; sp[2].epi = kv8 ? EPI_STORE : EPI_V_CACHE; sp[2].out = kv8 ? v_new : Lw.vcache; sp[2].bias = Lw.bv;
+    // flag-ordered: this launch runs beside the previous layer's down projection and waits for ITS records
+    for (int i = 0; i < 3; i++) sp[i].flag_wait_first = c->flag_qkv_wait;
+    c->flag_qkv_wait = kFlagNone;
     if ((rc = launch_mv(c, LGH_K_QKV, sp, 3, Lw.attn_norm, H))) return rc;
   } else {
     float* kt = c->kv_tmp;
@@ -529,6 +555,16 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
          })))
       return rc;
     xq_stale(c, c->attn_out);
+  } else if (c->attn_fuse) {
+    // split attention, merged by whichever split arrives last: no combine launch
+    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
+           return attn_fused_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, c->state + ST_POS,
+                                    c->n_splits, c->part_ml, c->part_acc, c->attn_arrive, c->attn_out, qa ? qa->xq : nullptr, c->stream);
+         })))
+      return rc;
+    if (qa) { qa->fresh = true; qa->tag = nullptr; }
+    else xq_stale(c, c->attn_out);
   } else {
   if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
@@ -563,6 +599,65 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     const uint32_t ks[3] = {Lw.wo.k, H, Lw.down.k};
     const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
     return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3);
+  }
+  uint32_t fe = c->flagging && !merge && li - c->l0 < c->flag_edges.size() ? c->flag_edges[li - c->l0] : 0u;
+  if (c->flow_mode && !(fe & 8u)) fe = 0;   // (flow launches and two-stream pairs are not mixed in one graph)
+  if (fe) {
+    // wo | gate-up | down | the next layer's QKV as flag-ordered launches on two streams (handoff.h).  Across an OVERLAPPED
+    // edge (bit 0: wo -> gate-up, bit 1: gate-up -> down, bit 2: down -> next QKV; chosen at finalize, where both launches
+    // fit on a CU together) the consumer goes to the other stream, is dispatched while its producer runs, has its first
+    // weight tiles in flight and then waits for the producer's records by counter.  The other stream must have caught up
+    // with everything BEFORE the producer (at most two of these launches are ever in flight): it has when the previous edge
+    // was overlapped too (it carries the producer's producer), otherwise an event edge is recorded in front of the producer.
+    // Across an edge that is not overlapped the consumer simply follows on the producer's stream.  Same kernels' arithmetic
+    // either way: the results are bit-identical to the single-stream graph (tests/test_gpu_model.py).
+    const uint32_t* cnt = &c->flag_cnt[(li - c->l0) * 3];
+    if (c->flow_mode && (fe & 8u)) {
+      // ONE launch for wo | gate-up | down: the three ops' workgroups side by side, ordered by the same counters (mvq_flow_kernel)
+      SegSpec sp[3];
+      sp[0].W[0] = &Lw.wo; sp[0].x[0] = c->attn_out; sp[0].epi = EPI_RESID; sp[0].out = c->hidden; sp[0].resid = c->hidden; sp[0].bias = Lw.bo;
+      sp[0].xq_next = 2; sp[0].xq_next_nw = Lw.ffn_norm; sp[0].flag_sig_first = cnt[0];
+      sp[1].npass = 2; sp[1].W[0] = &Lw.gate; sp[1].W[1] = &Lw.up; sp[1].x[0] = sp[1].x[1] = c->hidden; sp[1].epi = EPI_SWIGLU;
+      sp[1].out = c->act; sp[1].xq_next = 1; sp[1].flag_wait_first = cnt[0]; sp[1].flag_sig_first = cnt[1];
+      sp[2].W[0] = &Lw.down; sp[2].x[0] = c->act; sp[2].epi = EPI_RESID; sp[2].out = c->hidden; sp[2].resid = c->hidden;
+      sp[2].xq_next = next_mfma ? 2 : 0; sp[2].xq_next_nw = next_nw; sp[2].flag_wait_first = cnt[1];
+      const float* nws[3] = {nullptr, Lw.ffn_norm, nullptr};
+      const uint32_t ks[3] = {Lw.wo.k, H, Lw.down.k};
+      const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
+      return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3, true);
+    }
+    const bool e1 = fe & 1u, e2 = fe & 2u, e3 = fe & 4u;
+    hipStream_t cur = c->stream, oth = flag_other(c, cur);
+    // ---- wo
+    if (e1 && (rc = flag_edge(c, cur, oth))) return rc;          // the other stream catches up with the attention
+    SegSpec so;
+    so.W[0] = &Lw.wo; so.x[0] = c->attn_out; so.epi = EPI_RESID; so.out = c->hidden; so.resid = c->hidden; so.bias = Lw.bo;
+    so.xq_next = 2; so.xq_next_nw = Lw.ffn_norm; so.flag_sig_first = e1 ? cnt[0] : kFlagNone;
+    if ((rc = launch_mv(c, LGH_K_WO, &so, 1, nullptr, Lw.wo.k))) return rc;
+    // ---- gate/up
+    if (e1) std::swap(cur, oth);
+    else if (e2 && (rc = flag_edge(c, cur, oth))) return rc;     // ... with wo
+    c->stream = cur;
+    SegSpec sg;
+    sg.npass = 2; sg.W[0] = &Lw.gate; sg.W[1] = &Lw.up; sg.x[0] = sg.x[1] = c->hidden; sg.epi = EPI_SWIGLU; sg.out = c->act; sg.xq_next = 1;
+    sg.flag_wait_first = e1 ? cnt[0] : kFlagNone; sg.flag_sig_first = e2 ? cnt[1] : kFlagNone;
+    if ((rc = launch_mv(c, LGH_K_GATEUP, &sg, 1, Lw.ffn_norm, H))) return rc;
+    // ---- down
+    if (e2) std::swap(cur, oth);                                 // (e1: that stream carries wo; else the edge above)
+    else if (e3 && (rc = flag_edge(c, cur, oth))) return rc;     // ... with gate/up
+    c->stream = cur;
+    SegSpec sd;
+    sd.W[0] = &Lw.down; sd.x[0] = c->act; sd.epi = EPI_RESID; sd.out = c->hidden; sd.resid = c->hidden;
+    sd.xq_next = next_mfma ? 2 : 0; sd.xq_next_nw = next_nw;
+    sd.flag_wait_first = e2 ? cnt[1] : kFlagNone; sd.flag_sig_first = e3 ? cnt[2] : kFlagNone;
+    if ((rc = launch_mv(c, LGH_K_DOWN, &sd, 1, nullptr, Lw.down.k))) return rc;
+    // ---- the next layer continues on ...
+    if (e3) {
+      std::swap(cur, oth);                                       // ... the other stream, beside down (e2: it carries gate/up; else the edge above)
+      c->flag_qkv_wait = cnt[2];
+    }
+    c->stream = cur;
+    return LGH_OK;
   }
   if (merge) {
     SegSpec sp;
@@ -865,6 +960,10 @@ static int enqueue_token(lgh_ctx* c, int mode) {
   if (c->pt[mode].usable) return enqueue_token_pt(c, mode);
   const lgh_model_desc& d = c->d;
   int rc;
+  const int bump = c->flagging ? 1 : 0;
+  c->flag_origin = c->stream;
+  c->flag_qkv_wait = kFlagNone;
+  c->flag_ev_next = 0;
   for (auto& q : c->xqs) q.fresh = false;   // the residual stream is (re)written in f32 now (embedding / previous stage)
   if (c->first) {
     // the embedding row, and — when the first layer's QKV runs on the matrix cores — its XQ image with that layer's norm weights
@@ -876,12 +975,12 @@ static int enqueue_token(lgh_ctx* c, int mode) {
     }
     if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
            return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state,
-                               qh ? qh->xq : nullptr, nw0, qh ? qh->ssq : nullptr, c->stream);
+                               qh ? qh->xq : nullptr, nw0, qh ? qh->ssq : nullptr, c->stream, bump);
          })))
       return rc;
     if (qh) { qh->fresh = true; qh->tag = nw0; }
   } else {
-    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream, bump); }))) return rc;
   }
   for (uint32_t li = c->l0; li < c->l1; li++) {
     // who consumes this layer's output: the next layer's QKV (attn_norm), the output projection (output_norm), or — at a
@@ -895,7 +994,11 @@ static int enqueue_token(lgh_ctx* c, int mode) {
       next_nw = c->output_norm;
       next_mfma = mfma_type(c->output.type);
     }
-    if ((rc = layer_forward(c, li, next_nw, next_mfma, mode))) return rc;
+    if ((rc = layer_forward(c, li, next_nw, next_mfma, mode))) { c->stream = c->flag_origin; return rc; }
+  }
+  if (c->flag_ev_next) {   // flag-ordered launches were enqueued: whatever the other stream still carries joins the origin here
+    c->stream = c->flag_origin;
+    if ((rc = flag_edge(c, c->stream2, c->flag_origin))) return rc;
   }
   if (c->last && mode != MODE_PREFILL) {
     // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
@@ -926,15 +1029,28 @@ static int warm_kernels(lgh_ctx* c) {
     if ((v == 1 && c->direct_attn_max_kv == 0) || (v == 2 && c->merge_attn_max_kv == 0)) continue;
     c->attn_direct = v == 1;
     c->attn_merge = v == 2;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
     for (int mode : {c->last ? MODE_GREEDY : MODE_PREFILL, MODE_PREFILL})   // the last stage: with and without the output head
       if (!rc) rc = enqueue_token(c, mode);
+  }
+  if (!rc && c->flag_mode) {
+    // the flag-ordered instantiations must also have been launched once outside a capture (the trap described above); eagerly
+    // the two streams and their events work exactly as they do in the captured graph
+    c->attn_direct = c->attn_merge = false;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+    c->flagging = true;
+    rc = enqueue_token(c, c->last ? MODE_GREEDY : MODE_PREFILL);
+    c->flagging = false;
+    (void)hipStreamSynchronize(c->stream2);
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
+    // the warm-up token went through the counters like any other: the epoch word must survive the state reset below
   }
   c->attn_direct = keep_direct;
   c->attn_merge = keep_merge;
   for (auto& q : c->xqs) q.fresh = false;
   if (rc) return rc;
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   return check_chain(c);
 }
@@ -945,7 +1061,9 @@ static int ensure_graph(lgh_ctx* c, int mode) {
   hipGraph_t g = nullptr;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
   c->chain_pending.clear();
+  c->flagging = c->flag_mode;
   int rc = enqueue_token(c, mode);
+  c->flagging = false;
   hipError_t e = hipStreamEndCapture(c->stream, &g);
   for (ChainSlot* slot : c->chain_pending) {   // descriptor images of the chained launches (static per mode and layer)
     if (rc || e != hipSuccess || slot->uploaded) continue;
@@ -994,6 +1112,21 @@ static int check_chain(lgh_ctx* c) {
     unsigned flag = 0;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->pt[m].sync + 16, 4, hipMemcpyDeviceToHost));
     if (flag) return fail(c, LGH_OPERATION_FAILED, "a hand-off wait of the persistent token kernel timed out (code " + std::to_string(flag) + ")");
+  }
+  if (c->flag_sync) {   // a flag-ordered launch whose wait ran into its spin limit
+    unsigned f2 = 0;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&f2, c->flag_sync + 16, 4, hipMemcpyDeviceToHost));
+    if (f2) {
+      unsigned w[4] = {0, 0, 0, 0};
+      int ep = 0;
+      (void)hipMemcpy(w, c->flag_sync + 16, 16, hipMemcpyDeviceToHost);
+      (void)hipMemcpy(&ep, c->state + ST_EPOCH, 4, hipMemcpyDeviceToHost);
+      std::string where = "?";
+      for (size_t i = 0; i < c->flag_cnt.size(); i++)   // which launch's records the waiter was after
+        if (c->flag_cnt[i] != kFlagNone && c->flag_cnt[i] <= w[1]) where = "layer " + std::to_string(c->l0 + i / 3) + (i % 3 == 0 ? " wo" : i % 3 == 1 ? " gate/up" : " down");
+      return fail(c, LGH_OPERATION_FAILED, "a hand-off wait of a flag-ordered launch timed out (records of " + where + ", counter " + std::to_string(w[1]) +
+                  ": target " + std::to_string(w[2]) + ", seen " + std::to_string(w[3]) + ", token epoch " + std::to_string(ep) + ")");
+    }
   }
   if (!c->chain_sync) return LGH_OK;
   unsigned flag = 0;
@@ -1242,6 +1375,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   }
   if (splits > 32) splits = 32;   // the split merge keeps one partial per split in registers
   c->n_splits = splits;
+  c->attn_fuse = (d.flags & LGH_FLAG_ATTN_FUSED) != 0;
   const uint32_t dsel = (d.flags >> LGH_FLAG_ATTN_DIRECT_SHIFT) & 0xFFu;
   c->direct_attn_max_kv = dsel == 255 ? 0 : dsel ? dsel * 64 : kDirectAttnDefaultKv;
   // split + merge-in-wo: contexts up to 64 * n rows (bits 24..31; 0 = the tuned default, 255 = never).  Needs the output
@@ -1429,6 +1563,7 @@ int lgh_finalize(lgh_ctx* c) {
       {(void**)&c->act, ffn * 4},
       {(void**)&c->act2, ffn * 4},
       {(void**)&c->logits, (size_t)d.vocab_size * 4},
+      {(void**)&c->attn_arrive, (size_t)d.num_kv_heads * 16 * 4},
       {(void**)&c->part_ml, (size_t)d.num_kv_heads * c->n_splits * G * 2 * 4},
       {(void**)&c->part_acc, (size_t)d.num_kv_heads * c->n_splits * G * d.head_dim * 4},
       {(void**)&c->rope_cs, (size_t)d.max_seq_len * d.head_dim * 4},
@@ -1478,6 +1613,78 @@ int lgh_finalize(lgh_ctx* c) {
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   c->finalized = true;
   c->pos = 0;
+  if ((d.flags & (LGH_FLAG_OVERLAP | LGH_FLAG_FLOW_FFN)) && !(d.flags & (LGH_FLAG_NO_GRAPH | LGH_FLAG_CHAIN_FFN | LGH_FLAG_PERSISTENT)) && d.hidden_size % 256 == 0 &&
+      (d.num_heads * d.head_dim) % 256 == 0) {
+    // flag-ordered graphs (handoff.h): across which edges of wo -> gate-up -> down -> next QKV the consumer may be dispatched
+    // beside its producer.  A consumer spins on counters while it waits: it must never hold a CU that a workgroup of its
+    // producer still needs, so BOTH launches must fit on a CU together — registers (two waves per SIMD each, 512 per SIMD
+    // lane) and LDS — and then every CU has room for one workgroup of each (no launch has more workgroups than CUs).
+    // MEASURED (tools/ov_debug.py, Llama-3-8B): a Q6_K down projection at 144 registers beside a 120-register gate-up
+    // deadlocked now and then (its workgroups took the CUs that gate-up's last workgroups were still to be placed on).
+    auto fmt_mask = [](int dev_type) -> uint32_t {
+      return dev_type == kDevQ4K_T16 ? 1u : dev_type == kDevQ6K_T16 ? 2u : dev_type == kDevQ5K_T16 ? 4u : dev_type == kDevQ80_T16 ? 8u : dev_type == kDevQ40_T16 ? 16u : 0u;
+    };
+    struct Fit { int regs; size_t lds; };
+    auto fit_of = [&](uint32_t mask, uint32_t k, int npass) -> Fit {
+      const int r = mask ? mvq_kernel_regs(mask, true) : -1;
+      // LDS: the XQ records of the input (8 waves' k-slices together: the whole vector) + partial sums + slack
+      return {r <= 0 ? -1 : (r + 7) / 8 * 8, (size_t)k / 256 * kXqRecord + (size_t)npass * 8192 + 1024};
+    };
+    auto fits = [](const Fit& a, const Fit& b) { return a.regs > 0 && b.regs > 0 && a.regs + b.regs <= 256 && a.lds + b.lds <= 160 * 1024; };
+    auto qkv_fit = [&](const LayerW& L) -> Fit {
+      if (!(fused_type(L.wq.type) && fused_type(L.wk.type) && fused_type(L.wv.type)) || d.use_neox_rope) return {-1, 0};
+      if (!(mfma_type(L.wq.type) && mfma_type(L.wk.type) && mfma_type(L.wv.type))) return {-1, 0};
+      return fit_of(fmt_mask(L.wq.type) | fmt_mask(L.wk.type) | fmt_mask(L.wv.type), d.hidden_size, 1);
+    };
+    const bool flow_wanted = (d.flags & LGH_FLAG_FLOW_FFN) != 0;
+    c->flag_cnt.assign((size_t)(c->l1 - c->l0) * 3, kFlagNone);
+    c->flag_edges.assign((size_t)(c->l1 - c->l0), 0u);
+    uint32_t ncnt = 0;
+    for (uint32_t i = c->l0; i < c->l1; i++) {
+      const LayerW& L = c->layers[i];
+      if (L.moe() || d.intermediate_size % 256 || L.gate.type != L.up.type) {
+        if (std::getenv("LGH_DEBUG_OVERLAP")) std::fprintf(stderr, "[lgh] layer %u: moe %d, gate type %d, up type %d\n", i, (int)L.moe(), L.gate.type, L.up.type);
+        continue;
+      }
+      bool ok = true;
+      for (const DevWeight* W : {&L.wo, &L.gate, &L.up, &L.down}) ok = ok && mfma_type(W->type) && W->n % 16 == 0;
+      if (std::getenv("LGH_DEBUG_OVERLAP") && !ok)
+        std::fprintf(stderr, "[lgh] layer %u: types wo %d gate %d up %d down %d not all on the matrix cores\n", i, L.wo.type, L.gate.type, L.up.type, L.down.type);
+      if (!ok) continue;
+      const Fit fw = fit_of(fmt_mask(L.wo.type), L.wo.k, 1), fg = fit_of(fmt_mask(L.gate.type), d.hidden_size, 2),
+                fd = fit_of(fmt_mask(L.down.type), d.intermediate_size, 1);
+      uint32_t e = 0;
+      if (fits(fw, fg)) e |= 1u;
+      if (fits(fg, fd)) e |= 2u;
+      if (i + 1 < c->l1 && fits(fd, qkv_fit(c->layers[i + 1]))) e |= 4u;
+      // flow launch (one launch for the three ops): every op's body under half the registers, twice the largest LDS need fits
+      if (flow_wanted && fw.regs <= 128 && fg.regs <= 128 && fd.regs <= 128 && 2 * std::max(fw.lds, std::max(fg.lds, fd.lds)) <= 160 * 1024) e |= 8u;
+      if (std::getenv("LGH_DEBUG_OVERLAP"))
+        std::fprintf(stderr, "[lgh] layer %u: wo %d regs %zu B, gate/up %d regs %zu B, down %d regs %zu B -> edges %u\n", i, fw.regs, fw.lds, fg.regs,
+                     fg.lds, fd.regs, fd.lds, e);
+      if (!e) continue;
+      c->flag_edges[i - c->l0] = e;
+      uint32_t* cnt = &c->flag_cnt[(size_t)(i - c->l0) * 3];
+      cnt[0] = ncnt; ncnt += d.hidden_size / 256;
+      cnt[1] = ncnt; ncnt += d.intermediate_size / 256;
+      cnt[2] = ncnt; ncnt += d.hidden_size / 256;
+    }
+    if (ncnt) {
+      const size_t words = kHoHeader + (size_t)(ncnt + 1) * kHoCntStride;
+      if ((rc = dev_alloc(c, (void**)&c->flag_sync, words * 4))) return rc;
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemset(c->flag_sync, 0, words * 4));
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+      c->flag_events.assign((size_t)(c->l1 - c->l0) * 2 + 8, nullptr);
+      for (auto& e : c->flag_events) HIP_TRY(c, LGH_OPERATION_FAILED, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->flag_mode = true;
+      if (flow_wanted) {
+        c->flows.assign((size_t)MODE_COUNT * d.num_layers, ChainSlot{});
+        for (auto& slot : c->flows)   // device images allocated here, never during a graph capture
+          if ((rc = dev_alloc(c, (void**)&slot.dev, sizeof(MvLaunch) * kChainMaxOps + sizeof(MvChainOp) * kChainMaxOps))) return rc;
+        c->flow_mode = true;
+      }
+    }
+  }
   {  // the persistent token kernel's programs, one per graph mode (allocated here, never during a graph capture)
     const uint32_t G = d.num_heads / d.num_kv_heads;
     uint32_t smax = kNumCU / d.num_kv_heads;
@@ -1499,6 +1706,9 @@ void lgh_destroy(lgh_ctx* c) {
       if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
+  for (hipEvent_t e : c->flag_events)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->pf.tok_pinned) (void)hipHostFree(c->pf.tok_pinned);
   if (c->pf.tok_copied) (void)hipEventDestroy(c->pf.tok_copied);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1683,6 +1893,9 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
     if (c->last) b += c->output.bytes + (uint64_t)d.hidden_size * 4 + (uint64_t)d.vocab_size * 4;
   }
   c->stats.step_alg_bytes = b;
+  c->stats.overlapped_edges = 0;
+  if (c->flag_mode)
+    for (uint32_t e : c->flag_edges) c->stats.overlapped_edges += (uint64_t)__builtin_popcount(e);
   *out = c->stats;
   return LGH_OK;
 }

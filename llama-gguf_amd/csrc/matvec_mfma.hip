@@ -28,6 +28,7 @@
 #include "mv_epilogue.h"
 #include "xq.h"
 #include "mvq_core.h"
+#include "handoff.h"
 
 namespace lgh {
 
@@ -378,7 +379,8 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 // MASK: the formats (1 << F_*) the instantiation handles; with more than one the segment's type decides at run time
 // COH: the op runs inside a chain (mvq_chain_kernel): its inputs may have been written earlier in the same launch by
 // workgroups on other XCDs, and its outputs are read later in the same launch — agent-scope loads / write-through stores.
-template <uint32_t MASK, bool COH, bool ATTN = false>
+// FLAG: a flag-ordered launch (MvLaunch::flag_*, handoff.h; implies COH): tiles first, then the wait for the input's records.
+template <uint32_t MASK, bool COH, bool ATTN = false, bool FLAG = false, bool FLOW = false>
 __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                          uint32_t lds_red_off, const MvLaunch& L, uint8_t* smem8) {
   // the position word (RoPE epilogues): its scalar load goes out with the very first kernarg loads, no wait here
@@ -393,6 +395,10 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   const float* S_xq_nw = S.xq_nw;
   const float* L_rope_cs = L.rope_cs;
   constexpr bool kSingle = (MASK & (MASK - 1)) == 0;
+  // weight tiles in flight per wave.  A flag-ordered launch shares its CU with its producer (two workgroups, half the
+  // registers each): the two formats with 5-load tiles keep a ring of three there, which brings every single-format
+  // flag-ordered instantiation under 128 registers — ANY two of them then fit side by side (test_build_props.py)
+    constexpr int kDp = FLAG && (MASK == (1u << F_Q6K) || MASK == (1u << F_Q80)) ? kDepth - 1 : kDepth;
   const int fmt = kSingle ? __builtin_ctz(MASK) : fmt_of_dev_type(S.type);
   auto is = [&](int f) { return ((MASK >> f) & 1u) != 0 && (kSingle || fmt == f); };   // compile-time false for absent formats
   const uint32_t tb = is(F_Q4K) ? fmt_tile_bytes(F_Q4K) : is(F_Q6K) ? fmt_tile_bytes(F_Q6K) : is(F_Q5K) ? fmt_tile_bytes(F_Q5K)
@@ -460,13 +466,31 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   const float* L_ssq_part = L.ssq_part;
   const uint32_t L_n_ssq = L.n_ssq_part;
   float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (nrm && wave == 0) {
+  auto load_ssp = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (lane + 64 * j < L_n_ssq) ssp[j] = coh_load<COH>(L_ssq_part + lane + 64 * j);
-  }
+  };
+  if (!FLAG && nrm && wave == 0) load_ssp();
+  // flag-ordered launch: the producer of the input vector may still be running.  A wave waits for the records of its own
+  // k-slice; wave 0, which adds up ALL the producer's sums of squares when there is a norm, for every record.
   MvEpiPre epi_pre = {0.0f, 0.0f, false};
-  mv_epilogue_prefetch_resid<COH>(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
+  bool flag_synced = !FLAG;
+  auto flag_sync = [&]() {
+    if (flag_synced) return;
+    flag_synced = true;
+    if (L.flag_sync && L.flag_wait_first != kFlagNone) {
+      unsigned ep;
+      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(L.flag_epoch) : "memory");
+      const bool all = nrm && wave == 0;
+      const uint32_t first = all ? 0u : blk0, cnt = all ? S_nblk : nblk_w;
+      for (uint32_t b = 0; b < cnt; b += 64) ho_wait(L.flag_sync, L.flag_wait_first + first + b, min(64u, cnt - b), ep * 256u, lane);
+    }
+    if (nrm && wave == 0) load_ssp();
+  };
+  // FLOW (several ops in one launch): the residual of an op that waits is a vector an EARLIER op of the same launch rewrites
+  // (wo's output is down's residual) — not valid yet; the epilogue loads it itself then
+  if (!(FLOW && L.flag_wait_first != kFlagNone)) mv_epilogue_prefetch_resid<COH>(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pos_now));   // long since there: the kernarg batch above was waited for
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
@@ -552,8 +576,8 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
       LGH_WSTAMP(4);
     };
 
-    RawT16 buf[kDepth];
-    Pos pos[kDepth];
+    RawT16 buf[kDp];
+    Pos pos[kDp];
     // `run` for a static number of tiles put in flight up front; every path ends with nothing in flight
     auto run = [&](auto n_first) {
       constexpr int NF = decltype(n_first)::value;
@@ -564,6 +588,14 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
 #pragma unroll
         for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
         mvq_gather_attn(L.attn_ml, L.attn_acc, L.attn_splits, L.attn_g, L.attn_dshift, blk0, nblk_w, const_cast<uint8_t*>(xrec), lane);
+      } else if constexpr (FLAG) {
+        // the weight tiles do not depend on anything: in flight before the producer of x is even done; then its counters,
+        // then the records (agent-scope loads); everything issued so far has landed when the records have
+#pragma unroll
+        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+        flag_sync();
+        x_request();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         x_request();
 #pragma unroll
@@ -571,27 +603,27 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
         x_finish(n_first);
       }
       LGH_WSTAMP(5);
-      if constexpr (NF < kDepth) {   // that was everything
+      if constexpr (NF < kDp) {   // that was everything
 #pragma unroll
         for (int j = 0; j < NF; j++) consume(pos[j], buf[j]);
       } else {
-        uint32_t rem = nitems;       // not yet consumed; kDepth of them in flight
-        while (rem >= 2 * kDepth) {
+        uint32_t rem = nitems;       // not yet consumed; kDp of them in flight
+        while (rem >= 2 * kDp) {
 #pragma unroll
-          for (int j = 0; j < kDepth; j++) {
+          for (int j = 0; j < kDp; j++) {
             consume(pos[j], buf[j]);
             pos[j] = nx; issue(nx, buf[j]); advance();
           }
-          rem -= kDepth;
+          rem -= kDp;
         }
-        const uint32_t unissued = rem - kDepth;   // 0 .. kDepth-1
+        const uint32_t unissued = rem - kDp;   // 0 .. kDp-1
 #pragma unroll
-        for (int j = 0; j < kDepth; j++) {
+        for (int j = 0; j < kDp; j++) {
           consume(pos[j], buf[j]);
           if ((uint32_t)j < unissued) { pos[j] = nx; issue(nx, buf[j]); advance(); }
         }
 #pragma unroll
-        for (int j = 0; j < kDepth - 1; j++)
+        for (int j = 0; j < kDp - 1; j++)
           if ((uint32_t)j < unissued) consume(pos[j], buf[j]);
       }
     };
@@ -609,12 +641,13 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
     } else if (nitems == 3) {
       run(std::integral_constant<int, 3>{});
     } else {
-      run(std::integral_constant<int, kDepth>{});
+      run(std::integral_constant<int, kDp>{});
     }
     p0 = p1;
     LGH_STAMP(3);
     LGH_WSTAMP(6);
   }
+  if constexpr (FLAG) flag_sync();   // (a wave without tiles has not waited yet)
   if (nrm && wave == 0) {   // the producer's partial sums of x^2 -> ssq[0]; the other waves contribute nothing
     float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
     for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += coh_load<COH>(L_ssq_part + i);
@@ -626,6 +659,13 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   __syncthreads();
   LGH_STAMP(4);
   mv_epilogue<COH>(L, S, wg, red, ssq, S_T, epi_pre);
+  if constexpr (FLAG) {
+    if (L.flag_sync && L.flag_sig_first != kFlagNone && s == 0) {   // publish: stores drained by every wave, then one wave signals
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (wave == 0) ho_signal_rows(L.flag_sync, L.flag_sig_first, 8, wg * S_rpw, min(wg * S_rpw + S_rpw, S_nrows), lane);
+    }
+  }
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);
@@ -635,7 +675,23 @@ template <uint32_t MASK, bool ATTN = false>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  mvq_body<MASK, false, ATTN>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+  mvq_body<MASK, false, ATTN, false>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+}
+
+// Flag-ordered launches (handoff.h) run BESIDE their producer, two workgroups to a CU.  A consumer that waits on flags must
+// never hold a CU its producer still needs, so the engine pairs two launches only where both fit (mvq_kernel_regs): every
+// single-format instantiation stays under half the registers; the two mixed-format ones do not and run unpaired.
+template <uint32_t MASK>
+__global__ void __launch_bounds__(kWaves * 64) mvq_flag_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
+                                                               uint32_t lds_red_off, const MvLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  mvq_body<MASK, true, false, true>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+}
+using MvqKernelFn = void (*)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const MvLaunch);
+template <uint32_t MASK, bool ATTN, bool FLAG>
+static constexpr MvqKernelFn mvq_fn() {
+  if constexpr (!FLAG) return &mvq_kernel<MASK, ATTN>;
+  else return &mvq_flag_kernel<MASK>;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -701,6 +757,33 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_chain_kernel(const MvLaunch* 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Flow launch: several dependent mat-vecs (wo -> gate/up -> down) in ONE launch whose workgroups are SPLIT between the ops
+// (block ranges, in op order) instead of shared by them: the consumers' workgroups start with the launch, put their first
+// weight tiles in flight and wait for their producer's records by hand-off counter (handoff.h) — no kernel boundary and no
+// grid barrier between the ops, and a consumer's ramp-up hides under its producer's streaming.  Every instantiation of the
+// body stays under half the registers (two workgroups per CU).  Workgroups are dispatched in block order, so a producer's
+// workgroups are always placed before the consumers that wait for them: no wait can starve its producer of a CU.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kWaves * 64) mvq_flow_kernel(const MvLaunch* __restrict__ ops, const MvChainOp* __restrict__ geo, int nops) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  uint32_t bid = blockIdx.x;
+  int i = 0;
+  for (; i + 1 < nops; i++) {
+    const uint32_t n = geo[i].n_wg;
+    if (bid < n) break;
+    bid -= n;
+  }
+  const MvChainOp g = geo[i];
+  switch (g.pad0) {   // the op's format
+    case 1u << F_Q4K: mvq_body<(1u << F_Q4K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
+    case 1u << F_Q6K: mvq_body<(1u << F_Q6K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
+    case 1u << F_Q5K: mvq_body<(1u << F_Q5K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
+    case 1u << F_Q80: mvq_body<(1u << F_Q80), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
+    default: mvq_body<(1u << F_Q40), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host: geometry and launch
 // ------------------------------------------------------------------------------------------------
 hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows) {
@@ -715,7 +798,9 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   const uint32_t nbw = (nblk + T - 1) / T;
   if (launch_rows < n_rows) launch_rows = n_rows;
   const uint32_t tiles_launch = (launch_rows + 15) / 16;
-  uint32_t R = (tiles_launch + kNumCU - 1) / kNumCU;  // tiles per workgroup: one workgroup per CU
+  // tiles per workgroup: one workgroup per CU (two or three per CU, each with half / a third of the rows, measured the same
+  // to 1 %: 15.5 / 15.6 / 15.7 us for the Llama-3-8B gate-up launch — a launch is bound by its fixed costs, not by waves in flight)
+  uint32_t R = (tiles_launch + kNumCU - 1) / kNumCU;
   R = (R + G - 1) / G * G;
   const uint32_t threads = T * G * 64;
   const uint32_t rmax = threads / 16 / G * G;         // the epilogue gives every row (pair) a thread
@@ -735,14 +820,19 @@ size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
-template <uint32_t MASK, bool ATTN = false>
+template <uint32_t MASK, bool ATTN = false, bool FLAG = false>
 static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
                          uint32_t geom2, uint32_t red_off) {
   static bool attr_set[64] = {};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_kernel<MASK, ATTN>), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mvq_kernel<MASK, ATTN>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
+  constexpr MvqKernelFn fn = mvq_fn<MASK, ATTN, FLAG>();
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(fn), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL(fn, dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
   return hipGetLastError();
 }
+
+// registers per lane of the instantiation a launch with this format mask takes (flag-ordered or not): what the engine
+// checks before it lets two launches run side by side
+int mvq_kernel_regs(uint32_t mask, bool flag);
 
 // launch-uniform geometry of one op, packed for the kernel; returns the format mask (0 = not launchable)
 uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out) {
@@ -788,6 +878,15 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
       default: return hipErrorInvalidValue;
     }
   }
+  if (L.flag_sync) {   // flag-ordered launch (handoff.h)
+#define LGH_MVQ_FCASE(M) case M: return mvq_go<M, false, true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
+    switch (mask) {
+      LGH_MVQ_FCASE(1u << F_Q4K); LGH_MVQ_FCASE(1u << F_Q6K); LGH_MVQ_FCASE(1u << F_Q5K); LGH_MVQ_FCASE(1u << F_Q80); LGH_MVQ_FCASE(1u << F_Q40);
+      LGH_MVQ_FCASE((1u << F_Q4K) | (1u << F_Q6K)); LGH_MVQ_FCASE((1u << F_Q5K) | (1u << F_Q6K));
+      default: return hipErrorInvalidValue;
+    }
+#undef LGH_MVQ_FCASE
+  }
 #define LGH_MVQ_CASE(M) case M: return mvq_go<M>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
   switch (mask) {   // single formats and the two mixes of the "_M" quantisations (fused QKV: V in Q6_K)
     LGH_MVQ_CASE(1u << F_Q4K); LGH_MVQ_CASE(1u << F_Q6K); LGH_MVQ_CASE(1u << F_Q5K); LGH_MVQ_CASE(1u << F_Q80); LGH_MVQ_CASE(1u << F_Q40);
@@ -795,6 +894,30 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
     default: return hipErrorInvalidValue;   // other mixes: the caller launches one format at a time
   }
 #undef LGH_MVQ_CASE
+}
+
+int mvq_kernel_regs(uint32_t mask, bool flag) {
+  hipFuncAttributes a{};
+  const void* fn = nullptr;
+#define LGH_MVQ_RCASE(M) case M: fn = flag ? reinterpret_cast<const void*>(mvq_fn<M, false, true>()) : reinterpret_cast<const void*>(mvq_fn<M, false, false>()); break
+  switch (mask) {
+    LGH_MVQ_RCASE(1u << F_Q4K); LGH_MVQ_RCASE(1u << F_Q6K); LGH_MVQ_RCASE(1u << F_Q5K); LGH_MVQ_RCASE(1u << F_Q80); LGH_MVQ_RCASE(1u << F_Q40);
+    LGH_MVQ_RCASE((1u << F_Q4K) | (1u << F_Q6K)); LGH_MVQ_RCASE((1u << F_Q5K) | (1u << F_Q6K));
+    default: return -1;
+  }
+#undef LGH_MVQ_RCASE
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return -1;
+  return a.numRegs;
+}
+
+uint32_t mvq_format_mask(const MvLaunch& L) {
+  uint32_t m = 0;
+  for (int i = 0; i < L.nseg; i++) {
+    const int f = fmt_of_dev_type(L.seg[i].type);
+    if (f < 0) return 0;
+    m |= 1u << f;
+  }
+  return m;
 }
 
 // ---- chains
@@ -818,6 +941,37 @@ hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uin
   for (int i = 0; i < nops; i++)
     if (threads[i] != h->threads) return hipErrorInvalidValue;   // one launch geometry for all ops
   return hipSuccess;
+}
+
+// ---- flow launches
+hipError_t mvq_flow_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h) {
+  if (nops < 2 || nops > kChainMaxOps) return hipErrorInvalidValue;
+  h->nops = nops;
+  h->mask = 0;
+  h->lds = 0;
+  h->threads = threads[0];
+  uint32_t total = 0;
+  for (int i = 0; i < nops; i++) {
+    size_t lds = 0;
+    const uint32_t m = mvq_pack(Ls[i], n_wg[i], threads[i], &h->geo[i], &lds);
+    // one format per op, one launch geometry; no op with more workgroups than CUs (two workgroups fit on a CU)
+    if (!m || (m & (m - 1)) || n_wg[i] > (uint32_t)kNumCU || threads[i] != h->threads || !Ls[i].flag_sync) return hipErrorInvalidValue;
+    h->geo[i].pad0 = m;
+    h->op[i] = Ls[i];
+    h->mask |= m;
+    h->lds = std::max(h->lds, lds);
+    total += n_wg[i];
+  }
+  if (h->lds * 2 > 160 * 1024) return hipErrorInvalidValue;   // (a consumer's workgroup shares its CU with a producer's)
+  h->geo[0].pad1 = total;
+  return hipSuccess;
+}
+
+hipError_t mvq_flow_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, hipStream_t st) {
+  static bool attr_set[64] = {};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_flow_kernel), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL(mvq_flow_kernel, dim3(h.geo[0].pad1), dim3(h.threads), h.lds, st, dev_ops, dev_geo, h.nops);
+  return hipGetLastError();
 }
 
 template <uint32_t MASK>

@@ -382,6 +382,8 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
   Tmp t(device);
   if (t.rc) return t.rc;
   if (!avg_us || iters <= 0) return LGH_INVALID_ARGUMENT;
+  const bool two_streams = (mode & 16) != 0;
+  mode &= 15;
   const uint32_t be = blk_elems((int)type);
   if (!be || k % be) return LGH_SHAPE_MISMATCH;
   const size_t nbytes = n * (k / be) * blk_bytes((int)type);
@@ -395,6 +397,12 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
     if ((rc = upload_matrix(t.c, Ws[i], (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w, nbytes))) return rc;
     if (mode == 2 && (rc = upload_matrix(t.c, W2s[i], (int)type, (uint32_t)k, (uint32_t)n, 1, -1, w2 ? w2 : w, nbytes))) return rc;
   }
+  // mode bit 4 (experiment): consecutive launches alternate between two streams with nothing ordering them — how much of a
+  // launch's fixed cost hides behind its neighbour when the hardware may overlap them
+  hipStream_t s2 = nullptr;
+  if (two_streams && hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return LGH_OPERATION_FAILED;
+  hipStream_t s1 = t.c->stream;
+  int flip = 0;
   int cur = 0;
   std::vector<float> hx(k), hw(k, 1.0f);
   for (size_t i = 0; i < k; i++) hx[i] = 0.001f * (float)((i * 2654435761u) % 2001) - 1.0f;
@@ -404,6 +412,7 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
     DevWeight& W = Ws[cur];
     DevWeight& W2 = W2s[cur];
     cur = (cur + 1) % copies;
+    if (two_streams) { t.c->stream = (flip ^= 1) ? s2 : s1; for (auto& q : t.c->xqs) q.fresh = true; }
     if (mode == 2) {
       SegSpec sp;
       sp.npass = 2;
@@ -422,11 +431,21 @@ int lgh_bench_vec_mat(int device, uint32_t type, const void* w, const void* w2, 
 #ifdef LGH_STAMPS
   (void)lgh::mvq_spans(nullptr, 1);
 #endif
-  (void)hipEventRecord(a, t.c->stream);
+  if (two_streams) { (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s2); t.c->stream = s1; }
+  (void)hipEventRecord(a, s1);
+  if (two_streams) { (void)hipStreamWaitEvent(s2, a, 0); }
   for (int i = 0; i < iters; i++)
     if ((rc = once())) break;
-  (void)hipEventRecord(b, t.c->stream);
+  if (two_streams) {   // b on s1 after both streams have drained
+    hipEvent_t j;
+    (void)hipEventCreateWithFlags(&j, hipEventDisableTiming);
+    (void)hipEventRecord(j, s2);
+    (void)hipStreamWaitEvent(s1, j, 0);
+    t.c->stream = s1;
+  }
+  (void)hipEventRecord(b, s1);
   hipError_t e = hipEventSynchronize(b);
+  if (s2) { (void)hipStreamSynchronize(s2); (void)hipStreamDestroy(s2); }
   float ms = 0.0f;
   if (e == hipSuccess) e = hipEventElapsedTime(&ms, a, b);
   (void)hipEventDestroy(a);

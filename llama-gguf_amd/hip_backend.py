@@ -49,6 +49,9 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)
+FLAG_OVERLAP = 32      # flag-ordered mat-vec launches on two streams of the token graph (opt-in: measured slower; LGH_OVERLAP=1 sets it too)
+FLAG_FLOW_FFN = 64     # wo | gate-up | down as one launch ordered by hand-off counters (opt-in: measured slower; LGH_FLOW=1 sets it too)
+FLAG_ATTN_FUSED = 128  # split attention merged by the last-arriving split, no combine launch (opt-in: measured slower; LGH_ATTN_FUSED=1 sets it too)
 FLAG_KV_INT8 = 16   # KV cache in the reference's int8 format (kv_quantized.rs: int8 rows + one scale per head and position)
 FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
 
@@ -92,7 +95,7 @@ class Stats(C.Structure):
                 ("k_alg_bytes", C.c_uint64 * K_COUNT),
                 ("sym_launches", C.c_uint64 * SYM_COUNT), ("sym_time_us", C.c_double * SYM_COUNT),
                 ("sym_alg_bytes", C.c_uint64 * SYM_COUNT), ("step_alg_bytes", C.c_uint64),
-                ("event_bracket_us", C.c_double), ("event_bracket_samples", C.c_uint64)]
+                ("event_bracket_us", C.c_double), ("event_bracket_samples", C.c_uint64), ("overlapped_edges", C.c_uint64)]
 
 
 _lib = None
@@ -208,6 +211,9 @@ class HipGpuInference:
             flags |= FLAG_CHAIN_FFN
         if os.environ.get("LGH_PERSISTENT", "") not in ("", "0"):
             flags |= FLAG_PERSISTENT
+        for env, bit in (("LGH_OVERLAP", FLAG_OVERLAP), ("LGH_FLOW", FLAG_FLOW_FFN), ("LGH_ATTN_FUSED", FLAG_ATTN_FUSED)):
+            if os.environ.get(env, "") not in ("", "0"):
+                flags |= bit
         # attn_direct / attn_merge: 64-row units, 0 = tuned default, 255 = never
         d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16) | ((attn_merge & 0xFF) << 24)
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
@@ -346,7 +352,7 @@ class HipGpuInference:
         s = Stats()
         self._call(load_library().lgh_get_stats(self._h, C.byref(s)))
         out = {k: getattr(s, k) for k in ("weight_bytes", "kv_bytes", "scratch_bytes", "tokens_processed",
-                                          "graph_nodes", "step_alg_bytes", "event_bracket_us")}
+                                          "graph_nodes", "step_alg_bytes", "event_bracket_us", "overlapped_edges")}
         out["kernels"] = {K_NAMES[i]: {"launches": s.k_launches[i], "time_us": s.k_time_us[i],
                                        "alg_bytes": s.k_alg_bytes[i]}
                           for i in range(len(K_NAMES)) if s.k_launches[i]}

@@ -46,6 +46,22 @@ def test_mfma_kernel_fits_two_waves_per_simd():
         assert u["VGPRs"] <= 256 and u.get("Occupancy", 2) >= 2, (fn, u)
 
 
+def test_flag_ordered_instantiations_fit_two_workgroups_per_cu():
+    """A flag-ordered launch shares its CU with its producer (handoff.h): every single-format instantiation and the flow
+    kernel (wo | gate-up | down in one launch) must stay within 128 registers — four waves per SIMD, two workgroups of eight
+    waves per CU — whatever the pairing.  The two mixed-format instantiations do not; the engine never pairs them."""
+    usage = _usage("matvec_mfma.hip")
+    flag = {fn: u for fn, u in usage.items() if "mvq_flag_kernel" in fn or "mvq_flow_kernel" in fn}
+    assert len(flag) == 8   # five formats, two mixes, the flow kernel
+    small = 0
+    for fn, u in flag.items():
+        mixed = "ILj3E" in fn or "ILj6E" in fn
+        if not mixed:
+            assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u.get("Occupancy", 4) >= 4, (fn, u)
+            small += 1
+    assert small == 6
+
+
 def test_persistent_token_kernel_has_no_scratch():
     """The opt-in persistent token kernel keeps its tile ring, the attention state and the epilogue operands in registers
     (a per-op opaque thread id stops the lane constants from being hoisted across the op loop, decode_persistent.hip)."""

@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--only", default="")
+    ap.add_argument("--two-streams", action="store_true", help="alternate launches between two unordered streams (overlap experiment)")
     ap.add_argument("--copies", type=int, default=0, help="weight copies cycled through (0 = enough to stay cold; 1 = hot in the Infinity Cache)")
     args = ap.parse_args()
     pkg = graft.load_package()
@@ -40,7 +41,7 @@ def main():
         w = syn.fill_tensor("bench.weight", t, k * n, k)
         nbytes = w.nbytes * (2 if mode == 2 else 1)
         copies = args.copies if args.copies > 0 else max(2, min(32, int(600e6 // nbytes) + 1))
-        us = hb.bench_vec_mat(t, w, k, n, mode=mode, iters=args.iters, copies=copies)
+        us = hb.bench_vec_mat(t, w, k, n, mode=mode | (16 if args.two_streams else 0), iters=args.iters, copies=copies)
         print(f"{label:40s} {us:9.2f} us  {nbytes / us / 1e3:8.1f} GB/s  ({nbytes / 1e6:.1f} MB, {copies} copies)", flush=True)
 
 
