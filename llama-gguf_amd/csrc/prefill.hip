@@ -54,6 +54,9 @@ static int pf_fmt_of(int dev_type) {
 
 // waves per workgroup: 4 (one per SIMD, 4 row tiles each).  8 waves of 2 tiles (-DPF_WAVES=8: two per SIMD, twice the LDS
 // reads per MFMA) measured the same 4.68 ms per 128-token Llama-3-8B prompt: the loop is not latency-bound.
+#ifndef PF_EXP
+#define PF_EXP 0
+#endif
 #ifndef PF_WAVES
 #define PF_WAVES 4
 #endif
@@ -61,6 +64,26 @@ constexpr int kPfWaves = PF_WAVES;
 constexpr int kPfRT = 16 / kPfWaves;     // row tiles per wave (a workgroup covers 256 rows)
 constexpr int kPfMT = kPfTokens / 16;    // token tiles of a full block
 constexpr float kPfScale = 256.0f;
+
+#ifdef LGH_STAMPS
+// diagnostic build: per-workgroup phase stamps (100 MHz s_memrealtime) of the GEMM launches whose output is LGH_PF_STAMP_COLS wide
+#ifndef LGH_PF_STAMP_COLS
+#define LGH_PF_STAMP_COLS 28672
+#endif
+__device__ unsigned long long g_pf_stamps[1024 * 16];
+#define LGH_PF_STAMP(i)                                                                                         \
+  do {                                                                                                          \
+    if (G.ncols == LGH_PF_STAMP_COLS && threadIdx.x == 0 && (i) < 16) {                                         \
+      const uint32_t wgid = blockIdx.y * gridDim.x + blockIdx.x;                                                \
+      if (wgid < 1024) g_pf_stamps[wgid * 16 + (i)] = __builtin_amdgcn_s_memrealtime();                         \
+    }                                                                                                           \
+  } while (0)
+hipError_t pf_read_stamps(unsigned long long* host, size_t n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pf_stamps), std::min(n, (size_t)1024 * 16) * 8);
+}
+#else
+#define LGH_PF_STAMP(i)
+#endif
 
 struct PfRaw { u32x4 hd; u32x4 q[4]; };
 
@@ -214,14 +237,20 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     }
   };
 
+  LGH_PF_STAMP(0);
   PfRaw nxt[kPfRT];
   if (b0 < b1) {
     x_dma(b0, 0);
 #pragma unroll
     for (int r = 0; r < kPfRT; r++) pf_load<F>(nxt[r], wt[r] + (size_t)b0 * tb, lane, n);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (the BUILTIN, not inline asm: hipcc's wait-count pass must see that nothing is outstanding past this point.  With an
+  // asm wait it still counted the previous block's weight loads as pending and protected their first uses with
+  // `s_waitcnt vmcnt(21..12)` — in the hardware's count those are the NEXT slab's 16 LDS-DMA loads, issued just before, so
+  // every block began by waiting for part of the next slab.  They come from L2: 4.86 -> 4.80 ms per prompt pass.)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __syncthreads();
+  LGH_PF_STAMP(1);
   for (uint32_t b = b0; b < b1; b++) {
     const uint32_t cur = (b - b0) & 1;
     PfRaw w[kPfRT];
@@ -236,9 +265,12 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     // The block's 32 units (MFMA step pp, half h, row tile r) as a software pipeline, one scheduling region per unit:
     // the unit's 8 MFMAs, the dequantization of the NEXT unit's A fragment, and — in the first unit of a (pp, h) phase —
     // the LDS reads of the next phase's activation fragments.  Measured on Llama-3-8B Q4_K_M (128 tokens, 4.9 ms): with
-    // the LDS reads removed 4.89 ms, with the dequantization removed 4.19 ms — a 16-cycle MFMA holds the vector issue
-    // port for 8 cycles and each of the ~2.7 VALU ops per MFMA for 4 more, so the loop is VALU-issue-bound; forcing an
-    // MFMA / VALU interleave with sched_group_barrier changed nothing (4.94 vs 4.88 ms).
+    // the LDS reads removed 4.89 ms, with the dequantization removed 4.19 ms; forcing an MFMA / VALU interleave with
+    // sched_group_barrier changed nothing (4.94 vs 4.88 ms).  Phase stamps of the gate|up GEMM (tools/pf_phases.py, the PF_EXP
+    // switches below; 224 workgroups, 256 MFMAs + ~720 VALU ops per wave and block): 4.3 us per block as written, 3.3 us with
+    // MFMAs only (no dequantization, no LDS reads: 1.3 PFLOP/s chip-wide, what f16 MFMAs sustain here with every CU issuing
+    // them), 3.7 us with the dequantization and LDS reads only — the two overlap to within 30 %, the wait + barrier at the end
+    // of a block is 0.2 us.  The loop runs at 77 % of its MFMA-only rate.
     const uint8_t* xb = smem + cur * kPfSlabBytes + n * 512;
     h16x8 bf[2][MT];
     h16x2 S[kPfRT], O[kPfRT];
@@ -257,17 +289,31 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
       const int ph = u / kPfRT, r = u % kPfRT;
       if (u + 1 < 8 * kPfRT) {
         const int ph2 = (u + 1) / kPfRT, r2 = (u + 1) % kPfRT, pp2 = ph2 >> 1, h2 = ph2 & 1;
+#if PF_EXP == 1 || PF_EXP == 3   /* experiment: no dequantization */
+        af[(u + 1) & 1] = __builtin_bit_cast(h16x8, w[r2].q[pp2 & 1]);
+#else
         if (h2 == 0) pf_scale<F>(w[r2], pp2, n, c, S[r2], O[r2]);
         af[(u + 1) & 1] = pf_frag<F>(w[r2], pp2, h2, S[r2], O[r2]);
+#endif
       }
+#if PF_EXP == 2   /* experiment: no MFMAs (the fragment is folded into one accumulator so that it stays live) */
+      acc[r][0] += __builtin_bit_cast(f32x4, af[u & 1]) * __builtin_bit_cast(f32x4, bf[ph & 1][u & 7]);
+#else
 #pragma unroll
       for (int t = 0; t < MT; t++) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1], bf[ph & 1][t], acc[r][t], 0, 0, 0);
+#endif
       const bool rd = r == 0 && ph + 1 < 8;
+#if PF_EXP == 3   /* experiment: no LDS reads either */
+      if (rd) { for (int t = 0; t < MT; t++) bf[(ph + 1) & 1][t] = bf[ph & 1][t] + af[u & 1]; }
+#else
       if (rd) read_bf(ph + 1, bf[(ph + 1) & 1]);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LGH_PF_STAMP(2 + 2 * (b - b0 < 5 ? b - b0 : 5));
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     __syncthreads();
+    LGH_PF_STAMP(3 + 2 * (b - b0 < 5 ? b - b0 : 5));
   }
   // partial sums: lane holds, per (row tile, token tile), rows 4c .. 4c+3 of token n
   uint32_t row0 = 0;
@@ -284,6 +330,10 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
       *reinterpret_cast<f32x4*>(part + (size_t)(t * 16 + n) * G.ncols + col) = v;
     }
   }
+#ifdef LGH_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  LGH_PF_STAMP(14);
 }
 
 template <uint32_t MASK>

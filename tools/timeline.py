@@ -5,9 +5,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+anchor = sys.argv[3] if len(sys.argv) > 3 else "embed_kernel"     # the kernel a step starts with ("embed_batch_kernel": a prompt pass)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "embed_kernel" in r["Kernel_Name"]]
-a, b = starts[-back - 1], starts[-back]
+starts = [i for i, r in enumerate(rows) if anchor in r["Kernel_Name"]]
+a = starts[-back - 1]
+b = starts[-back] if back > 0 else len(rows) - 1
 t0 = int(rows[a]["Start_Timestamp"])
 prev_end = t0
 tot = {}
