@@ -82,7 +82,16 @@ typedef struct lgh_model_desc {
   uint32_t layer_begin;
   uint32_t layer_end;
   uint32_t flags;                    /* LGH_FLAG_* */
+  uint32_t kv_cache_type;            /* LGH_KV_*: the reference's KVCacheFormat (src/model/kv_quantized.rs:11-20; `--kv-cache-type`).
+                                        0 = f32, or int8 when LGH_FLAG_KV_INT8 is set (the field was added after the flag) */
 } lgh_model_desc;
+
+enum {
+  LGH_KV_F32 = 0,
+  LGH_KV_INT8 = 1,                   /* int8 rows + one f32 scale per (kv head, position) */
+  LGH_KV_FP8_E4M3 = 2,               /* one byte per element, no scales: the reference's quantize_fp8_e4m3 (mantissa truncated) */
+  LGH_KV_FP8_E5M2 = 3,
+};
 
 enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
@@ -322,6 +331,10 @@ int lgh_op_silu_mul(int device, const float* gate, const float* up, float* out, 
 int lgh_op_add(int device, const float* a, const float* b, float* out, size_t n);
 int lgh_op_mul(int device, const float* a, const float* b, float* out, size_t n);
 int lgh_op_scale(int device, const float* a, float scalar, float* out, size_t n);
+/* One row of n values through a KV cache format and back: quantize_int8 / quantize_fp8_e4m3 / quantize_fp8_e5m2 and their
+ * dequantizers (src/model/kv_quantized.rs:385-565) as the attention launch applies them.  kv_cache_type LGH_KV_INT8 /
+ * LGH_KV_FP8_E4M3 / LGH_KV_FP8_E5M2; bytes_out[n]; *scale_out = the int8 row scale (1 for the FP8 formats; may be NULL). */
+int lgh_op_kv_roundtrip(int device, uint32_t kv_cache_type, const float* row, size_t n, uint8_t* bytes_out, float* scale_out, float* back_out);
 int lgh_op_silu(int device, const float* x, float* out, size_t n);
 int lgh_op_gelu(int device, const float* x, float* out, size_t n);
 int lgh_op_softmax(int device, const float* x, float* out, size_t rows, size_t last_dim);

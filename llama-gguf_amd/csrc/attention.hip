@@ -268,7 +268,56 @@ __device__ __forceinline__ uint32_t quantize_row_i8(f32x4 x, float& scale) {
   return qz(x.x) | qz(x.y) << 8 | qz(x.z) << 16 | qz(x.w) << 24;
 }
 
-template <int D, int G, int NW>
+// ---- the reference's FP8 KV formats (kv_quantized.rs:413-565; FMT 2 = E4M3, 3 = E5M2): one byte per element, no scales ----
+// dequantize_fp8_*: case by case it is the standard decode of the format (E4M3 without infinities, 0x7F / 0xFF = NaN), except
+// that both zeros read back as +0.  E5M2 is the upper byte of an IEEE half.
+template <int FMT>
+__device__ __forceinline__ float fp8_decode(uint32_t b) {
+  const uint32_t mag = b & 0x7Fu;
+  if (mag == 0) return 0.0f;
+  if (FMT == 3) return (float)__builtin_bit_cast(_Float16, (uint16_t)(b << 8));
+  if (mag == 0x7Fu) return __uint_as_float(0x7FC00000u);
+  const uint32_t e = mag >> 3, mt = mag & 7u;
+  const float v = e ? __uint_as_float((e + 120u) << 23 | mt << 20) : (float)mt * 0x1p-9f;
+  return __uint_as_float(__float_as_uint(v) | (b & 0x80u) << 24);
+}
+// quantize_fp8_e4m3 / _e5m2 as written in the reference: the mantissa is truncated, magnitudes past the largest exponent
+// saturate to 0x7E / 0x7C, and an E4M3 magnitude in [480, 512) becomes the NaN pattern 0x7F
+template <int FMT>
+__device__ __forceinline__ uint32_t fp8_encode(float value) {
+  constexpr bool e4 = FMT == 2;
+  const uint32_t bits = __float_as_uint(value);
+  const uint32_t sign = (bits >> 31) << 7;
+  if (value != value) return 0xFFu;
+  if ((bits & 0x7FFFFFFFu) == 0x7F800000u) return e4 ? (sign ? 0xFFu : 0x7Fu) : (sign ? 0xFCu : 0x7Cu);
+  if (value == 0.0f) return 0x00u;
+  const int exponent = (int)((bits >> 23) & 0xFFu) - 127;
+  uint32_t mantissa = bits & 0x7FFFFFu;
+  if (exponent != -127) mantissa |= 0x800000u;
+  if (e4) {
+    const int e = exponent + 7;
+    if (e > 15) return sign | 0x7Eu;
+    if (e > -3 && e <= 0) return sign | ((mantissa >> (24 - (uint32_t)(3 + e))) & (0x7u >> (uint32_t)(-e)));
+    if (e <= -3) return sign;
+    return sign | (uint32_t)e << 3 | ((mantissa >> 20) & 0x7u);
+  }
+  const int e = exponent + 15;
+  if (e > 31) return sign | 0x7Cu;
+  if (e >= -1 && e <= 0) return sign | ((mantissa >> (24 - (uint32_t)(2 + e))) & (0x3u >> (uint32_t)(-e)));
+  if (e < -1) return sign;
+  return sign | (uint32_t)e << 2 | ((mantissa >> 21) & 0x3u);
+}
+// four cached values of one dword, any byte format (FMT 1 = int8 with the row's scale)
+template <int FMT>
+__device__ __forceinline__ f32x4 unpack_kv4(uint32_t w, float scale) {
+  if (FMT == 1) return unpack_i8x4(w, scale);
+  f32x4 r;
+  r.x = fp8_decode<FMT>(w & 0xFFu); r.y = fp8_decode<FMT>((w >> 8) & 0xFFu);
+  r.z = fp8_decode<FMT>((w >> 16) & 0xFFu); r.w = fp8_decode<FMT>(w >> 24);
+  return r;
+}
+
+template <int D, int G, int NW, int FMT>
 __global__ void __launch_bounds__(NW * 64) attn_partial_q8_kernel(const float* __restrict__ q, int8_t* __restrict__ k8, int8_t* __restrict__ v8,
                                                                   float* __restrict__ kscale, float* __restrict__ vscale,
                                                                   const float* __restrict__ k_new, const float* __restrict__ v_new,
@@ -322,25 +371,32 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_q8_kernel(const float* _
       const uint32_t p = base + j * stride + sub, r = p < pos ? p : pos - 1;
       kk[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(k8 + (hrow + r) * D + li * 4));
       vv[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(v8 + (hrow + r) * D + li * 4));
-      ks[j] = kscale[hrow + r];
-      vs[j] = vscale[hrow + r];
+      ks[j] = FMT == 1 ? kscale[hrow + r] : 1.0f;
+      vs[j] = FMT == 1 ? vscale[hrow + r] : 1.0f;
     }
 #pragma unroll
     for (int j = 0; j < kAhead; j++)
-      if (base + j * stride < pos) step(base + j * stride + sub < pos, unpack_i8x4(kk[j], ks[j]), unpack_i8x4(vv[j], vs[j]));
+      if (base + j * stride < pos) step(base + j * stride + sub < pos, unpack_kv4<FMT>(kk[j], ks[j]), unpack_kv4<FMT>(vv[j], vs[j]));
   }
   if (wave == 0) {   // the current token's row: quantized here (every split the same bits), stored by split 0
     const f32x4 kx = *reinterpret_cast<const f32x4*>(k_new + (size_t)kvh * D + li * 4);
     const f32x4 vx = *reinterpret_cast<const f32x4*>(v_new + (size_t)kvh * D + li * 4);
-    float ksc, vsc;
-    const uint32_t kq = quantize_row_i8<LPR>(kx, ksc), vq = quantize_row_i8<LPR>(vx, vsc);
+    float ksc = 1.0f, vsc = 1.0f;
+    uint32_t kq, vq;
+    if (FMT == 1) {
+      kq = quantize_row_i8<LPR>(kx, ksc);
+      vq = quantize_row_i8<LPR>(vx, vsc);
+    } else {
+      kq = fp8_encode<FMT>(kx.x) | fp8_encode<FMT>(kx.y) << 8 | fp8_encode<FMT>(kx.z) << 16 | fp8_encode<FMT>(kx.w) << 24;
+      vq = fp8_encode<FMT>(vx.x) | fp8_encode<FMT>(vx.y) << 8 | fp8_encode<FMT>(vx.z) << 16 | fp8_encode<FMT>(vx.w) << 24;
+    }
     if (sp == 0) {
       if (sub == 0) {
         *reinterpret_cast<uint32_t*>(k8 + (hrow + pos) * D + li * 4) = kq;
         *reinterpret_cast<uint32_t*>(v8 + (hrow + pos) * D + li * 4) = vq;
-        if (li == 0) { kscale[hrow + pos] = ksc; vscale[hrow + pos] = vsc; }
+        if (FMT == 1 && li == 0) { kscale[hrow + pos] = ksc; vscale[hrow + pos] = vsc; }
       }
-      step(sub == 0, unpack_i8x4(kq, ksc), unpack_i8x4(vq, vsc));
+      step(sub == 0, unpack_kv4<FMT>(kq, ksc), unpack_kv4<FMT>(vq, vsc));
     }
   }
 #pragma unroll
@@ -385,24 +441,68 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_q8_kernel(const float* _
 }
 
 template <int D, int G>
-static hipError_t attn_q8_go(const float* q, int8_t* k8, int8_t* v8, float* ks, float* vs, const float* k_new, const float* v_new, uint32_t n_kv,
+static hipError_t attn_q8_go(int fmt, const float* q, int8_t* k8, int8_t* v8, float* ks, float* vs, const float* k_new, const float* v_new, uint32_t n_kv,
                              uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
-  hipLaunchKernelGGL((attn_partial_q8_kernel<D, G, 4>), dim3(n_kv * n_splits), dim3(256), 0, st, q, k8, v8, ks, vs, k_new, v_new, max_seq, scale, pos,
-                     n_splits, part_ml, part_acc);
+#define LGH_Q8_GO(FMT)                                                                                                                          \
+  hipLaunchKernelGGL((attn_partial_q8_kernel<D, G, 4, FMT>), dim3(n_kv * n_splits), dim3(256), 0, st, q, k8, v8, ks, vs, k_new, v_new, max_seq, \
+                     scale, pos, n_splits, part_ml, part_acc)
+  if (fmt == 1) LGH_Q8_GO(1);
+  else if (fmt == 2) LGH_Q8_GO(2);
+  else if (fmt == 3) LGH_Q8_GO(3);
+  else return hipErrorInvalidValue;
+#undef LGH_Q8_GO
   return hipGetLastError();
 }
 
-hipError_t attn_q8_launch(const float* q, int8_t* k8, int8_t* v8, float* kscale, float* vscale, const float* k_new, const float* v_new,
+// fmt: lgh_model_desc.kv_cache_type (1 = int8 + scales, 2 = FP8 E4M3, 3 = FP8 E5M2; the scale arrays are unused for 2 and 3)
+hipError_t attn_q8_launch(int fmt, const float* q, int8_t* k8, int8_t* v8, float* kscale, float* vscale, const float* k_new, const float* v_new,
                           uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
                           float* part_ml, float* part_acc, hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || !pos) return hipErrorInvalidValue;
   const uint32_t g = n_heads / n_kv;
 #define LGH_ATTN_CASE(DD, GG) \
-  if (head_dim == DD && g == GG) return attn_q8_go<DD, GG>(q, k8, v8, kscale, vscale, k_new, v_new, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st);
+  if (head_dim == DD && g == GG) return attn_q8_go<DD, GG>(fmt, q, k8, v8, kscale, vscale, k_new, v_new, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st);
   LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
   LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
 #undef LGH_ATTN_CASE
   return hipErrorInvalidValue;
+}
+
+// one row of n values through a byte KV format and back (the quantizers of attn_partial_q8_kernel, stand-alone): bytes and,
+// for int8, the row's scale; `back` = what attention would read
+template <int FMT>
+__global__ void __launch_bounds__(64) kv_roundtrip_kernel(const float* __restrict__ x, uint32_t n, uint8_t* __restrict__ bytes,
+                                                          float* __restrict__ scale_out, float* __restrict__ back) {
+  const uint32_t lane = threadIdx.x;
+  float scale = 1.0f;
+  if (FMT == 1) {   // quantize_int8: one scale per row
+    float amax = 0.0f;
+    for (uint32_t i = lane; i < n; i += 64) amax = fmaxf(amax, fabsf(x[i]));
+    amax = wave_max(amax);
+    scale = amax > 1e-10f ? amax / 127.0f : 1.0f;
+    if (lane == 0) *scale_out = scale;
+  }
+  for (uint32_t i = lane; i < n; i += 64) {
+    uint32_t b;
+    if (FMT == 1) {
+      float r = roundf(x[i] / scale);
+      r = r < -128.0f ? -128.0f : (r > 127.0f ? 127.0f : r);
+      b = (uint32_t)(int)r & 0xFFu;
+      back[i] = (float)(int)(int8_t)b * scale;
+    } else {
+      b = fp8_encode<FMT>(x[i]);
+      back[i] = fp8_decode<FMT>(b);
+    }
+    bytes[i] = (uint8_t)b;
+  }
+}
+
+hipError_t kv_roundtrip_launch(int fmt, const float* x, uint32_t n, uint8_t* bytes, float* scale_out, float* back, hipStream_t st) {
+  if (fmt == 1) hipLaunchKernelGGL(kv_roundtrip_kernel<1>, dim3(1), dim3(64), 0, st, x, n, bytes, scale_out, back);
+  else if (fmt == 2) hipLaunchKernelGGL(kv_roundtrip_kernel<2>, dim3(1), dim3(64), 0, st, x, n, bytes, scale_out, back);
+  else if (fmt == 3) hipLaunchKernelGGL(kv_roundtrip_kernel<3>, dim3(1), dim3(64), 0, st, x, n, bytes, scale_out, back);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
 }
 
 // out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}.  Lane s of the first wave owns split s

@@ -232,7 +232,9 @@ hipError_t attn_direct_launch(const float* q, const float* kcache, const float* 
                               uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st);
 bool attn_shape_has_fast_kernel(uint32_t head_dim, uint32_t group);
 // decode attention over the int8 KV cache (kv_quantized.rs); k_new / v_new: the current token's f32 rows [n_kv][D]
-hipError_t attn_q8_launch(const float* q, int8_t* k8, int8_t* v8, float* kscale, float* vscale, const float* k_new, const float* v_new,
+// one row through a byte KV format (lgh_model_desc.kv_cache_type 1..3) and back
+hipError_t kv_roundtrip_launch(int fmt, const float* x, uint32_t n, uint8_t* bytes, float* scale_out, float* back, hipStream_t st);
+hipError_t attn_q8_launch(int fmt, const float* q, int8_t* k8, int8_t* v8, float* kscale, float* vscale, const float* k_new, const float* v_new,
                           uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
                           float* part_ml, float* part_acc, hipStream_t st);
 hipError_t attn_decode_any_launch(const float* q, const float* kcache, const float* vcache, float* out, uint32_t n_heads, uint32_t n_kv,

@@ -514,12 +514,13 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   }
   // ---- attention_cached (ops.rs:1479-1537)
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
-  const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * (kv8 ? d.head_dim + 4 : d.head_dim * 4);
+  const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) *
+                            (d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4 : kv8 ? d.head_dim : d.head_dim * 4);
   const bool merge = c->attn_merge && !c->attn_direct && mfma_type(Lw.wo.type);
   if (kv8) {
     // int8 rows + scales (kv_quantized.rs); the launch also quantizes and stores the current token's rows
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
-           return attn_q8_launch(c->q, Lw.k8, Lw.v8, Lw.kscale, Lw.vscale, k_new, v_new, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
+           return attn_q8_launch((int)d.kv_cache_type, c->q, Lw.k8, Lw.v8, Lw.kscale, Lw.vscale, k_new, v_new, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
                                  scale, c->state + ST_POS, c->n_splits, c->part_ml, c->part_acc, c->stream);
          })))
       return rc;
@@ -1345,9 +1346,18 @@ int lgh_device_count(void) {
 }
 
 int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
-  if (!desc || !out || desc->struct_size != sizeof(lgh_model_desc)) return LGH_INVALID_ARGUMENT;
+  // (a descriptor from before kv_cache_type was appended is still taken: its cache type comes from the flags alone)
+  if (!desc || !out || (desc->struct_size != sizeof(lgh_model_desc) && desc->struct_size != offsetof(lgh_model_desc, kv_cache_type)))
+    return LGH_INVALID_ARGUMENT;
   *out = nullptr;
-  const lgh_model_desc& d = *desc;
+  lgh_model_desc d{};
+  std::memcpy(&d, desc, desc->struct_size);
+  d.struct_size = sizeof(lgh_model_desc);
+  if (d.kv_cache_type > LGH_KV_FP8_E5M2) return LGH_INVALID_ARGUMENT;
+  if (d.kv_cache_type == LGH_KV_F32 && (d.flags & LGH_FLAG_KV_INT8)) d.kv_cache_type = LGH_KV_INT8;
+  // every byte-per-element cache shares the int8 cache's structure (staged f32 rows, the attention launch quantizes and stores
+  // the current token's rows): the flag marks all of them from here on, kv_cache_type tells them apart
+  if (d.kv_cache_type != LGH_KV_F32) d.flags |= LGH_FLAG_KV_INT8;
   std::string why;
   if (int rc = engine_shape_check(d, why)) return rc;
   int ndev = lgh_device_count();
@@ -1537,11 +1547,13 @@ int lgh_finalize(lgh_ctx* c) {
         if ((rc = dev_alloc(c, (void**)p8, kv_elems))) return rc;
         HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*p8, 0, kv_elems, c->stream));
       }
+      const bool scales = d.kv_cache_type == LGH_KV_INT8;   // (the FP8 formats have none, kv_quantized.rs:31-35)
       for (float** ps : {&L.kscale, &L.vscale}) {
+        if (!scales) break;
         if ((rc = dev_alloc(c, (void**)ps, n_rows * 4))) return rc;
         HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*ps, 0, n_rows * 4, c->stream));
       }
-      c->stats.kv_bytes += 2 * (kv_elems + n_rows * 4);
+      c->stats.kv_bytes += 2 * (kv_elems + (scales ? n_rows * 4 : 0));
       continue;
     }
     // per-layer K/V [kv_heads, max_seq, head_dim] f32 (gpu_only.rs:555-572)
@@ -1829,7 +1841,8 @@ int lgh_kv_shift_left(lgh_ctx* c, size_t amount) {
     for (uint32_t li = c->l0; li < c->l1; li++) {
       LayerW& L = c->layers[li];
       if (d.flags & LGH_FLAG_KV_INT8) {
-        if ((rc = shift(L.k8, d.head_dim)) || (rc = shift(L.v8, d.head_dim)) || (rc = shift(L.kscale, 4)) || (rc = shift(L.vscale, 4))) return rc;
+        if ((rc = shift(L.k8, d.head_dim)) || (rc = shift(L.v8, d.head_dim))) return rc;
+        if (d.kv_cache_type == LGH_KV_INT8 && ((rc = shift(L.kscale, 4)) || (rc = shift(L.vscale, 4)))) return rc;
       } else if ((rc = shift(L.kcache, row)) || (rc = shift(L.vcache, row))) {
         return rc;
       }
@@ -1886,7 +1899,8 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
       if (L.moe()) b += (uint64_t)d.num_experts_per_token * (L.gate_exps.bytes + L.up_exps.bytes + L.down_exps.bytes) + (uint64_t)d.num_experts * d.hidden_size * 4;
       else b += L.gate.bytes + L.up.bytes + L.down.bytes;
       b += (uint64_t)2 * d.hidden_size * 4;                                       // norm weights
-      const uint64_t kv_row = (d.flags & LGH_FLAG_KV_INT8) ? d.head_dim + 4 : (uint64_t)d.head_dim * 4;   // int8 row + its scale
+      const uint64_t kv_row = d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4                                // int8 row + its scale
+                              : d.kv_cache_type != LGH_KV_F32 ? d.head_dim : (uint64_t)d.head_dim * 4;
       b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * kv_row;                  // KV read (kv_len = pos+1)
       b += (uint64_t)2 * d.num_kv_heads * kv_row;                                 // KV write
     }

@@ -250,6 +250,26 @@ int lgh_op_softmax(int device, const float* x, float* out, size_t rows, size_t l
   return t.down(out, dout, rows * last_dim);
 }
 
+int lgh_op_kv_roundtrip(int device, uint32_t kv_cache_type, const float* row, size_t n, uint8_t* bytes_out, float* scale_out, float* back_out) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (kv_cache_type < LGH_KV_INT8 || kv_cache_type > LGH_KV_FP8_E5M2) return LGH_UNSUPPORTED;
+  if (n == 0) return LGH_OK;
+  if (!row || !bytes_out || !back_out || n > 0x7FFFFFFFu) return LGH_INVALID_ARGUMENT;
+  float *dx = t.up(row, n), *dback = t.up(nullptr, n), *dsc = t.up(nullptr, 1);
+  uint8_t* db = reinterpret_cast<uint8_t*>(t.up(nullptr, (n + 3) / 4));
+  if (!dx || !dback || !dsc || !db) return LGH_ALLOCATION_FAILED;
+  if (kv_roundtrip_launch((int)kv_cache_type, dx, (uint32_t)n, db, dsc, dback, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  std::vector<float> tmp((n + 3) / 4);
+  int rc = t.down(tmp.data(), reinterpret_cast<float*>(db), (n + 3) / 4);
+  if (rc) return rc;
+  std::memcpy(bytes_out, tmp.data(), n);
+  float sc = 1.0f;
+  if (kv_cache_type == LGH_KV_INT8 && (rc = t.down(&sc, dsc, 1))) return rc;
+  if (scale_out) *scale_out = sc;
+  return t.down(back_out, dback, n);
+}
+
 int lgh_op_matmul(int device, const float* a, const float* b, float* out, size_t m, size_t k, size_t n) {
   Tmp t(device);
   if (t.rc) return t.rc;

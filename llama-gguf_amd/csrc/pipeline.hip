@@ -109,7 +109,7 @@ int sync_all(lgh_pipeline* p) {
 extern "C" {
 
 int lgh_pipeline_create(const lgh_model_desc* desc, const int* device_ids, int n_stages, lgh_pipeline** out) {
-  if (!desc || !out || n_stages < 1 || desc->struct_size != sizeof(lgh_model_desc)) return LGH_INVALID_ARGUMENT;
+  if (!desc || !out || n_stages < 1 || desc->struct_size != sizeof(lgh_model_desc)) return LGH_INVALID_ARGUMENT;   // (lgh_create re-checks per stage)
   *out = nullptr;
   if ((uint32_t)n_stages > desc->num_layers) return LGH_INVALID_ARGUMENT;
   lgh_pipeline* p = new lgh_pipeline();

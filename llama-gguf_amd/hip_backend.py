@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libllama_gguf_hip%s.so" % ("_" + os.envir
 ABI_SYMBOLS = (
     "lgh_device_count", "lgh_create", "lgh_upload_tensor", "lgh_finalize", "lgh_destroy", "lgh_forward",
     "lgh_prefill_token", "lgh_prefill_batch", "lgh_prefill_is_batched", "lgh_op_mat_mat",
-    "lgh_op_add", "lgh_op_mul", "lgh_op_scale", "lgh_op_silu", "lgh_op_gelu", "lgh_op_softmax", "lgh_op_matmul", "lgh_op_matvec",
+    "lgh_op_kv_roundtrip", "lgh_op_add", "lgh_op_mul", "lgh_op_scale", "lgh_op_silu", "lgh_op_gelu", "lgh_op_softmax", "lgh_op_matmul", "lgh_op_matvec",
     "lgh_op_matvec_q", "lgh_op_attention", "lgh_backend_create", "lgh_backend_destroy", "lgh_backend_load_weight",
     "lgh_backend_has_weight", "lgh_backend_vec_mat_q", "lgh_backend_last_error", "lgh_reset", "lgh_position", "lgh_kv_truncate", "lgh_kv_shift_left", "lgh_stage_prefill_batch", "lgh_stage_hidden_block_buffer", "lgh_forward_argmax", "lgh_decode_greedy",
     "lgh_last_error", "lgh_get_stats", "lgh_set_profiling", "lgh_set_stream", "lgh_get_stream", "lgh_synchronize",
@@ -48,6 +48,7 @@ SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_ke
              "lgh::mvq_kernel<8u, false>", "lgh::ptok_kernel")
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
+KV_F32, KV_INT8, KV_FP8_E4M3, KV_FP8_E5M2 = 0, 1, 2, 3   # lgh_model_desc.kv_cache_type (the reference's KVCacheFormat)
 FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)
 FLAG_OVERLAP = 32      # flag-ordered mat-vec launches on two streams of the token graph (opt-in: measured slower; LGH_OVERLAP=1 sets it too)
 FLAG_FLOW_FFN = 64     # wo | gate-up | down as one launch ordered by hand-off counters (opt-in: measured slower; LGH_FLOW=1 sets it too)
@@ -75,7 +76,7 @@ class ModelDesc(C.Structure):
         "use_neox_rope")]
                 + [(n, C.c_float) for n in ("norm_eps", "rope_freq_base", "rope_freq_scale")]
                 + [("device_id", C.c_int32), ("layer_begin", C.c_uint32), ("layer_end", C.c_uint32),
-                   ("flags", C.c_uint32)])
+                   ("flags", C.c_uint32), ("kv_cache_type", C.c_uint32)])
 
 
 class GgufInfo(C.Structure):
@@ -136,6 +137,7 @@ def load_library() -> C.CDLL:
         "lgh_op_norm_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_op_swiglu_vec_mat": (C.c_int, [C.c_int, u32, vp, vp, vp, vp, f32, vp, sz, sz]),
         "lgh_op_add": (C.c_int, [C.c_int, vp, vp, vp, sz]), "lgh_op_mul": (C.c_int, [C.c_int, vp, vp, vp, sz]),
+        "lgh_op_kv_roundtrip": (C.c_int, [C.c_int, C.c_uint32, vp, sz, vp, vp, vp]),
         "lgh_op_scale": (C.c_int, [C.c_int, vp, f32, vp, sz]), "lgh_op_silu": (C.c_int, [C.c_int, vp, vp, sz]),
         "lgh_op_gelu": (C.c_int, [C.c_int, vp, vp, sz]), "lgh_op_softmax": (C.c_int, [C.c_int, vp, vp, sz, sz]),
         "lgh_op_matmul": (C.c_int, [C.c_int, vp, vp, vp, sz, sz, sz]), "lgh_op_matvec": (C.c_int, [C.c_int, vp, vp, vp, sz, sz]),
@@ -190,7 +192,8 @@ class HipGpuInference:
     # -- pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>  (gpu_only.rs:426)
     @classmethod
     def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
-                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, attn_merge: int = 0) -> "HipGpuInference":
+                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, attn_merge: int = 0,
+                   kv_cache_type: int = 0) -> "HipGpuInference":
         """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
         `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
         L = load_library()
@@ -216,6 +219,7 @@ class HipGpuInference:
                 flags |= bit
         # attn_direct / attn_merge: 64-row units, 0 = tuned default, 255 = never
         d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16) | ((attn_merge & 0xFF) << 24)
+        d.kv_cache_type = int(kv_cache_type)
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size
         try:
@@ -546,6 +550,17 @@ def op_attention_cached(q, k_cache, v_cache, scale: float, kv_len: int, n_splits
                                                 q.shape[0], kc.shape[0], q.shape[1], kc.shape[1], scale, kv_len,
                                                 n_splits), "attention_cached")
     return out
+
+
+def op_kv_roundtrip(kv_cache_type: int, row, device: int = 0):
+    """One row through a KV cache format (KV_INT8 / KV_FP8_E4M3 / KV_FP8_E5M2) and back: (bytes, scale, values read back)."""
+    x = _f32(row)
+    b = np.zeros(x.size, dtype=np.uint8)
+    back = np.empty_like(x)
+    sc = C.c_float(1.0)
+    _chk(load_library().lgh_op_kv_roundtrip(device, kv_cache_type, x.ctypes.data, x.size, b.ctypes.data, C.addressof(sc),
+                                            back.ctypes.data), "kv_roundtrip")
+    return b, float(sc.value), back
 
 
 def op_silu_mul(gate, up, device: int = 0) -> np.ndarray:

@@ -65,6 +65,7 @@ struct orc_model {
   std::vector<float> embd_f32;  // dequantized table (kept unless faithful mode re-does it per call)
   std::vector<std::vector<float>> k_cache, v_cache;  // per layer [kv_heads][max_seq][head_dim]
   bool kv_int8 = false;                               // rows go through the reference's int8 KV format on their way into the cache
+  int kv_fp8 = 0;                                     // ... or through one of its FP8 formats (1: E4M3, 2: E5M2)
   std::vector<float> last_hidden;
   size_t position = 0;
   bool finalized = false;
@@ -142,6 +143,11 @@ int attention_forward(orc_model* m, size_t li, const float* x, size_t pos, float
         orc_kv_quantize_int8(row, d, q8.data(), &sc);
         orc_kv_dequantize_int8(q8.data(), sc, d, row);
       }
+  }
+  if (m->kv_fp8) {
+    // KVCacheFormat::Fp8E4M3 / Fp8E5M2 (kv_quantized.rs:190-205, 256-268): one byte per element, no scales
+    for (float* vec : {k.data(), v.data()})
+      for (size_t i = 0; i < nkv * d; i++) vec[i] = orc_kv_dequantize_fp8(m->kv_fp8, orc_kv_quantize_fp8(m->kv_fp8, vec[i]));
   }
   for (size_t h = 0; h < nkv; h++) {  // 577-600
     std::memcpy(kc + h * ms * d + pos * d, k.data() + h * d, d * 4);
@@ -311,7 +317,7 @@ int orc_model_finalize(orc_model* m) {
 void orc_model_reset(orc_model* m) { m->position = 0; }  // KVCache::reset (model/mod.rs:110-117): O(1)
 size_t orc_model_position(const orc_model* m) { return m->position; }
 
-void orc_model_set_kv_int8(orc_model* m, int on) { m->kv_int8 = on != 0; }
+void orc_model_set_kv_int8(orc_model* m, int on) { m->kv_int8 = on != 0; if (on) m->kv_fp8 = 0; }
 
 // quantize_int8 / dequantize_int8 (src/model/kv_quantized.rs:385-410): symmetric, scale = max|x| / 127 (1 when the row is
 // all ~zero), q = round(x / scale) (f32::round: half away from zero) clamped to [-128, 127]
@@ -329,6 +335,69 @@ void orc_kv_quantize_int8(const float* x, size_t n, int8_t* q, float* scale) {
 
 void orc_kv_dequantize_int8(const int8_t* q, float scale, size_t n, float* out) {
   for (size_t i = 0; i < n; i++) out[i] = (float)q[i] * scale;
+}
+
+void orc_model_set_kv_fp8(orc_model* m, int fmt) { m->kv_fp8 = (fmt == 1 || fmt == 2) ? fmt : 0; m->kv_int8 = false; }
+
+// quantize_fp8_e4m3 / quantize_fp8_e5m2 (src/model/kv_quantized.rs:413-449, 492-528) as written there: the f32 mantissa is
+// TRUNCATED (no rounding), magnitudes past the largest exponent saturate to 0x7E / 0x7C, and an E4M3 value whose exponent
+// field is 15 and whose three kept mantissa bits are all ones (|x| in [480, 512)) comes out as 0x7F — the NaN pattern.
+// fmt: 1 = E4M3 (bias 7, 3 mantissa bits), 2 = E5M2 (bias 15, 2 mantissa bits).
+uint8_t orc_kv_quantize_fp8(int fmt, float value) {
+  const bool e4 = fmt == 1;
+  if (std::isnan(value)) return 0xFF;
+  if (std::isinf(value)) return e4 ? (value > 0.0f ? 0x7F : 0xFF) : (value > 0.0f ? 0x7C : 0xFC);
+  if (value == 0.0f) return 0x00;
+  uint32_t bits;
+  std::memcpy(&bits, &value, 4);
+  const uint8_t sign = (uint8_t)((bits >> 31) & 1u);
+  const int exponent = (int)((bits >> 23) & 0xFFu) - 127;
+  uint32_t mantissa = bits & 0x7FFFFFu;
+  if (exponent != -127) mantissa |= 0x800000u;
+  if (e4) {
+    const int e = exponent + 7;
+    if (e > 15) return (uint8_t)((sign << 7) | 0x7E);
+    if (e > -3 && e <= 0) {
+      const uint32_t shift_bits = (uint32_t)(3 + e);
+      const uint32_t mask = 0x7u >> (uint32_t)(-e);
+      return (uint8_t)((sign << 7) | (uint8_t)((mantissa >> (24 - shift_bits)) & mask));
+    }
+    if (e <= -3) return (uint8_t)(sign << 7);
+    return (uint8_t)((sign << 7) | ((uint8_t)e << 3) | (uint8_t)((mantissa >> 20) & 0x7u));
+  }
+  const int e = exponent + 15;
+  if (e > 31) return (uint8_t)((sign << 7) | 0x7C);
+  if (e >= -1 && e <= 0) {
+    const uint32_t shift_bits = (uint32_t)(2 + e);
+    const uint32_t mask = 0x3u >> (uint32_t)(-e);
+    return (uint8_t)((sign << 7) | (uint8_t)((mantissa >> (24 - shift_bits)) & mask));
+  }
+  if (e < -1) return (uint8_t)(sign << 7);
+  return (uint8_t)((sign << 7) | ((uint8_t)e << 2) | (uint8_t)((mantissa >> 21) & 0x3u));
+}
+
+// dequantize_fp8_e4m3 / dequantize_fp8_e5m2 (kv_quantized.rs:452-489, 531-565), case by case as written there
+float orc_kv_dequantize_fp8(int fmt, uint8_t bits) {
+  const bool e4 = fmt == 1;
+  auto from_bits = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+  if ((bits & 0x7F) == 0) return 0.0f;
+  const uint32_t sign = (bits >> 7) & 1u;
+  if (e4) {
+    if ((bits & 0x7F) == 0x7F) return std::nanf("");
+    const uint32_t e = (bits >> 3) & 0xFu, mt = bits & 0x7u;
+    const uint32_t float_exp = (uint32_t)((int)e - 7 + 127);
+    if (e > 0) return from_bits(sign << 31 | float_exp << 23 | mt << 20);
+    if (mt >= 4) return from_bits(sign << 31 | float_exp << 23 | (mt & 3u) << 21);
+    if (mt > 1) return from_bits(sign << 31 | (float_exp - 1) << 23 | (mt & 1u) << 22);
+    return from_bits(sign << 31 | (float_exp - 2) << 23);   // mt == 1 (mt == 0 is the zero above)
+  }
+  if ((bits & 0x7F) == 0x7C) return sign ? -INFINITY : INFINITY;
+  if ((bits & 0x7F) >= 0x7D) return std::nanf("");
+  const uint32_t e = (bits >> 2) & 0x1Fu, mt = bits & 0x3u;
+  const uint32_t float_exp = (uint32_t)((int)e - 15 + 127);
+  if (e > 0) return from_bits(sign << 31 | float_exp << 23 | mt << 21);
+  if (mt >= 2) return from_bits(sign << 31 | float_exp << 23 | (mt & 1u) << 22);
+  return from_bits(sign << 31 | (float_exp - 1) << 23);     // mt == 1
 }
 
 void orc_model_kv_truncate(orc_model* m, size_t new_len) {  // KVCache::truncate (model/mod.rs:130-134)

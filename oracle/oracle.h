@@ -128,6 +128,11 @@ void orc_kv_quantize_int8(const float* x, size_t n, int8_t* q, float* scale);
 void orc_kv_dequantize_int8(const int8_t* q, float scale, size_t n, float* out);
 /* on: K/V rows pass through that format on their way into the cache (QuantizedKVCache::write_kv / read_k_range) */
 void orc_model_set_kv_int8(orc_model* m, int on);
+/* the reference's FP8 KV formats (kv_quantized.rs:413-565, KVCacheFormat::Fp8E4M3 / Fp8E5M2): fmt 1 = E4M3, 2 = E5M2 */
+uint8_t orc_kv_quantize_fp8(int fmt, float value);
+float orc_kv_dequantize_fp8(int fmt, uint8_t bits);
+/* fmt 1 / 2: K/V rows pass through that format on their way into the cache; 0: off */
+void orc_model_set_kv_fp8(orc_model* m, int fmt);
 /* debug taps: hidden state after the last forward's final layer (pre-norm) */
 int orc_model_last_hidden(const orc_model* m, float* out);
 

@@ -72,7 +72,8 @@ def lib() -> C.CDLL:
         "orc_attention": (None, [vp, vp, vp, vp, sz, sz, sz, sz, sz, C.c_float]),
         "orc_silu_mul_inplace": (None, [vp, vp, sz]), "orc_max_f32": (C.c_float, [vp, sz]), "orc_sum_f32": (C.c_float, [vp, sz]),
         "orc_kv_quantize_int8": (None, [vp, sz, vp, vp]), "orc_kv_dequantize_int8": (None, [vp, C.c_float, sz, vp]),
-        "orc_model_set_kv_int8": (None, [vp, C.c_int]),
+        "orc_model_set_kv_int8": (None, [vp, C.c_int]), "orc_model_set_kv_fp8": (None, [vp, C.c_int]),
+        "orc_kv_quantize_fp8": (C.c_uint8, [C.c_int, C.c_float]), "orc_kv_dequantize_fp8": (C.c_float, [C.c_int, C.c_uint8]),
         "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
         "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),
@@ -284,6 +285,18 @@ def kv_dequantize_int8(q, scale: float) -> np.ndarray:
     return out
 
 
+FP8_E4M3, FP8_E5M2 = 1, 2
+
+
+def kv_quantize_fp8(fmt: int, x: float) -> int:
+    """quantize_fp8_e4m3 / _e5m2 (kv_quantized.rs:413-449, 492-528): the byte."""
+    return int(lib().orc_kv_quantize_fp8(fmt, C.c_float(x)))
+
+
+def kv_dequantize_fp8(fmt: int, b: int) -> float:
+    return float(lib().orc_kv_dequantize_fp8(fmt, C.c_uint8(b)))
+
+
 def argmax_last(v) -> int:
     v = _f32(v)
     return int(lib().orc_argmax_last(_p(v), v.size))
@@ -315,6 +328,10 @@ class Model:
     def set_kv_int8(self, on: bool = True) -> None:
         """K/V rows go through the reference's int8 KV format (kv_quantized.rs) on their way into the cache."""
         lib().orc_model_set_kv_int8(self._h, int(on))
+
+    def set_kv_fp8(self, fmt: int) -> None:
+        """K/V rows go through one of the reference's FP8 KV formats (FP8_E4M3 / FP8_E5M2; 0 = off)."""
+        lib().orc_model_set_kv_fp8(self._h, int(fmt))
 
     def add_tensor(self, name: str, t: int, ne, data: np.ndarray) -> None:
         data = np.ascontiguousarray(data)

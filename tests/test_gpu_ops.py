@@ -171,3 +171,38 @@ def test_dequantize_activation_formats_bit_exact(gpu, orc, tname):
     got = gpu.op_dequantize(t, raw, x.size)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.abs(want - x).max() < 0.1                               # and the round trip is what the reference's bounds say
+
+
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+def test_kv_cache_formats_bit_exact(gpu, orc, fmt):
+    """The KV cache's byte formats as the attention launch applies them (lgh_op_kv_roundtrip; kv_cache_type 1 = int8, 2 = FP8
+    E4M3, 3 = FP8 E5M2) against the oracle's restatement of quantize_int8 / quantize_fp8_* and their dequantizers
+    (src/model/kv_quantized.rs:385-565): bytes, scale and read-back values identical — every exactly representable value, the
+    value just below the next one (the reference truncates), halves for int8's round-half-away, saturation, subnormals,
+    signed zeros, and (FP8) infinities and the [480, 512) magnitudes that encode to the NaN pattern."""
+    rng = np.random.default_rng(40 + fmt)
+    rows = [rng.standard_normal(256).astype(np.float32) * s for s in (1.0, 0.01, 300.0)]
+    rows.append(np.array([0.0, -0.0, 1e-12, -1e-12, 0.5, -1.5, 2.5, -2.5, 448.0, 500.0, -500.0, 57344.0, 70000.0, 1e9, -1e9,
+                          2.0 ** -6, 2.0 ** -9, 2.0 ** -10, 2.0 ** -14, 2.0 ** -16, 2.0 ** -17, 1.52588e-5, 0.0136719], np.float32))
+    if fmt != 1:
+        exact = np.array([orc.kv_dequantize_fp8(fmt - 1, b) for b in range(256)], np.float32)
+        exact = exact[np.isfinite(exact)]
+        rows += [exact, np.nextafter(exact, np.float32(0.0)), np.nextafter(exact, np.float32(np.inf) * np.sign(exact + np.float32(1e-30)))]
+        rows.append(np.array([np.inf, -np.inf], np.float32))
+    else:
+        rows.append(np.zeros(64, np.float32))                                   # an all-zero row: scale 1
+        rows.append((np.arange(-130, 131, dtype=np.float32) + np.float32(0.5)) * np.float32(127.0 / 130.5))   # halves
+    for row in rows:
+        got_b, got_sc, got_back = gpu.op_kv_roundtrip(fmt, row)
+        if fmt == 1:
+            want_q, want_sc = orc.kv_quantize_int8(row)
+            want_back = orc.kv_dequantize_int8(want_q, want_sc)
+            want_b = want_q.view(np.uint8)
+        else:
+            want_b = np.array([orc.kv_quantize_fp8(fmt - 1, float(v)) for v in row], np.uint8)
+            want_back = np.array([orc.kv_dequantize_fp8(fmt - 1, int(b)) for b in want_b], np.float32)
+            want_sc = 1.0
+        assert np.array_equal(got_b, want_b), (fmt, row[got_b != want_b][:4], got_b[got_b != want_b][:4], want_b[got_b != want_b][:4])
+        assert got_sc == np.float32(want_sc)
+        assert np.array_equal(got_back.view(np.uint32)[~np.isnan(want_back)], want_back.view(np.uint32)[~np.isnan(want_back)])
+        assert np.array_equal(np.isnan(got_back), np.isnan(want_back))

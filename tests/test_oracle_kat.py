@@ -280,3 +280,55 @@ def test_int8_kv_cache_kats(orc):
     assert sc == 1.0 and not q.any()
     q, sc = orc.kv_quantize_int8(np.array([0.5, -1.5, 2.5, -2.5], np.float32) * np.float32(2.5 / 127 * 127 / 2.5))
     assert list(q) == [25, -76, 127, -127]                       # f32::round: halves away from zero (25.4 -> 25, -76.2 -> -76)
+
+
+def _fp8_value(fmt, b):
+    """Independent decode of an FP8 byte (OCP E4M3 'fn' / E5M2): what the reference's dequantize_fp8_* must produce."""
+    ebits, mbits, bias = (4, 3, 7) if fmt == 1 else (5, 2, 15)
+    s = -1.0 if b & 0x80 else 1.0
+    e, m = (b >> mbits) & ((1 << ebits) - 1), b & ((1 << mbits) - 1)
+    if fmt == 1 and (b & 0x7F) == 0x7F:
+        return float("nan")
+    if fmt == 2 and e == 31:
+        return s * float("inf") if m == 0 else float("nan")
+    if e == 0:
+        return 0.0 if m == 0 else s * m * 2.0 ** (1 - bias - mbits)      # (the reference returns +0 for both zeros)
+    return s * (1.0 + m / (1 << mbits)) * 2.0 ** (e - bias)
+
+
+def test_fp8_kv_cache_kats(orc):
+    """The reference's FP8 KV formats (src/model/kv_quantized.rs:413-565): test_fp8_e4m3_roundtrip (:563-585),
+    test_fp8_e5m2_roundtrip (:588-609) and the FP8 legs of test_quantized_kv_cache_basic (:612-665) with their tolerances;
+    then every byte against an independent decode, the truncating (not rounding) encode, saturation, and the quirk that an
+    E4M3 magnitude in [480, 512) encodes to the NaN pattern 0x7F."""
+    for fmt, values, tol in ((orc.FP8_E4M3, [0.0, 1.0, -1.0, 0.5, 0.0136719, 448.0, 2.0 ** -6, 2.0 ** -9], 0.05),
+                             (orc.FP8_E5M2, [0.0, 1.0, -1.0, 0.5, 57344.0, 2.0 ** -14, 1.52588e-5], 0.1)):
+        for val in values:
+            d = orc.kv_dequantize_fp8(fmt, orc.kv_quantize_fp8(fmt, val))
+            if val == 0.0:
+                assert d == 0.0
+            elif abs(val) < 1e-5:
+                assert abs(d) < 0.01
+            else:
+                assert abs(val - d) / abs(val) < tol, (fmt, val, d)
+        k = np.arange(4 * 64, dtype=np.float32) * np.float32(0.01) - np.float32(1.0)
+        v = np.arange(4 * 64, dtype=np.float32) * np.float32(0.02) - np.float32(0.5)
+        for row in (k[:64], v[:64]):
+            for a in row:
+                b = orc.kv_dequantize_fp8(fmt, orc.kv_quantize_fp8(fmt, float(a)))
+                rel = abs(a - b) / abs(a) if abs(a) > 1e-6 else abs(a - b)
+                assert rel < 0.25, (fmt, a, b)
+        for byte in range(256):
+            want, got = _fp8_value(fmt, byte), orc.kv_dequantize_fp8(fmt, byte)
+            assert (np.isnan(want) and np.isnan(got)) or want == got, (fmt, byte, want, got)
+            if not np.isnan(want) and not np.isinf(want) and want != 0.0:
+                assert orc.kv_quantize_fp8(fmt, got) == byte                         # exact values encode to themselves
+                below_next = np.nextafter(np.float32(_fp8_value(fmt, byte + 1)), np.float32(0.0)).item() \
+                    if (byte & 0x7F) < (0x7E if fmt == orc.FP8_E4M3 else 0x7B) else None
+                if below_next is not None and not np.isnan(below_next):
+                    assert orc.kv_quantize_fp8(fmt, below_next) == byte, (fmt, byte)   # truncation: just below the next value stays here
+    assert orc.kv_quantize_fp8(orc.FP8_E4M3, 1e6) == 0x7E and orc.kv_quantize_fp8(orc.FP8_E4M3, -1e6) == 0xFE   # saturation to 448
+    assert orc.kv_quantize_fp8(orc.FP8_E5M2, 1e9) == 0x7C                                                        # ... and to inf
+    assert orc.kv_quantize_fp8(orc.FP8_E4M3, 500.0) == 0x7F and np.isnan(orc.kv_dequantize_fp8(orc.FP8_E4M3, 0x7F))
+    assert orc.kv_quantize_fp8(orc.FP8_E4M3, 2.0 ** -10) == 0x00 and orc.kv_quantize_fp8(orc.FP8_E5M2, 2.0 ** -17) == 0x00
+    assert orc.kv_quantize_fp8(orc.FP8_E4M3, float("nan")) == 0xFF and orc.kv_quantize_fp8(orc.FP8_E5M2, float("inf")) == 0x7C
