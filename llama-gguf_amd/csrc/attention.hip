@@ -17,6 +17,8 @@
 //     a tiny combine kernel across splits.
 // The reference CPU path skips softmax weights <= 1e-8 (ops.rs:1529); like the reference's own GPU
 // kernel this one does not (each skipped term is < 1e-8 of the output scale).
+#include <cstdlib>
+
 #include "device_utils.h"
 #include "xq.h"
 #include "prefill.h"
@@ -620,6 +622,149 @@ hipError_t attn_direct_launch(const float* q, const float* kcache, const float* 
   return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Causal attention of a block of prompt tokens on the matrix cores, in f32 (v_mfma_f32_16x16x4_f32: exact f32 products,
+// f32 accumulation — no f16 rounding enters here).  A workgroup = one query head x 16 tokens; its 4 waves take the kv tiles
+// (16 cached rows each) round-robin, each with its own online-softmax state, merged through LDS at the end.
+// Per kv tile a wave computes S^T = K Q^T (M = kv row, N = token; the contraction runs over d, lane group c owning the
+// D/4 contiguous dims [c D/4, (c+1) D/4) of both operands, so K and Q fragments are plain 16-byte loads) and then
+// O^T += V^T P^T: the D layout of S^T gives lane (token n, group c) the four kv rows 4c..4c+3 of token n, which is exactly
+// the B operand of four MFMAs whose contraction index c stands for kv row 4c+i — the probabilities never leave their
+// registers.  The A operand of those is V^T with output row m standing for dims D/16 m .. D/16 m + D/16 - 1 (contiguous
+// loads again).  The VALU kernel this replaces (still taken by other head sizes; LGH_PF_ATTN_VALU=1 forces it) spent 17 us per
+// layer of a 128-token Llama-3-8B prompt, bound by vector issue (four workgroups of four waves per CU); this one 10.7 us
+// (8 waves, the next tile's fragments in flight during a tile; 11.7 us with 4 waves), and the 512-token prompt 19.0 instead
+// of 21.8 ms.
+// ------------------------------------------------------------------------------------------------
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_pf_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kc, const float* __restrict__ vc,
+                                                               uint32_t n_heads, uint32_t g_per_kv, uint32_t max_seq, float scale, uint32_t pos0,
+                                                               uint32_t m_tokens, uint8_t* __restrict__ xh_out) {
+  constexpr int DJ = D / 4;    // contraction steps of S^T (dims per lane group)
+  constexpr int DQ = D / 16;   // output dims per M index
+  constexpr int DP = D + 4;    // padded row of the merge buffer
+  extern __shared__ __attribute__((aligned(16))) float pf_lds[];
+  float (*s_o)[16][DP] = reinterpret_cast<float (*)[16][DP]>(pf_lds);                 // [NW][16][DP]
+  float (*s_m)[16] = reinterpret_cast<float (*)[16]>(pf_lds + NW * 16 * DP);          // [NW][16]
+  float (*s_l)[16] = s_m + NW;
+  const uint32_t head = blockIdx.x, tt = blockIdx.y, kvh = head / g_per_kv;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n = lane & 15, c = lane >> 4;
+  const uint32_t tok = tt * 16 + n, tokc = tok < m_tokens ? tok : m_tokens - 1;
+  const uint32_t kv_last = pos0 + m_tokens - 1;                               // last cached row
+  const uint32_t n_tiles = (pos0 + tt * 16 + 16 + 15) / 16;                   // tiles the last token of this tile can see
+  float qf[DJ];
+  {
+    const float* qp = q + ((size_t)tokc * n_heads + head) * D + c * DJ;
+#pragma unroll
+    for (int j = 0; j < DJ; j += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qp + j);
+      qf[j] = v.x; qf[j + 1] = v.y; qf[j + 2] = v.z; qf[j + 3] = v.w;
+    }
+  }
+  const float* kbase = kc + (size_t)kvh * max_seq * D;
+  const float* vbase = vc + (size_t)kvh * max_seq * D;
+  float m_run = kNegBig, l_run = 0.0f;
+  f32x4 acc[DQ];
+#pragma unroll
+  for (int x = 0; x < DQ; x++) acc[x] = (f32x4)(0.0f);
+  // a tile's K fragment (row kv0 + n, dims [c DJ, (c+1) DJ)) and V fragments (rows kv0 + 4c + i, dims [n DQ, (n+1) DQ)); rows
+  // past the block are clamped here and masked below
+  f32x4 kn[DJ / 4], vn[4][DQ / 4];
+  auto load_tile = [&](uint32_t tile) {
+    const uint32_t kv0 = tile * 16;
+    const uint32_t kr = kv0 + n < kv_last ? kv0 + n : kv_last;
+    const float* kp = kbase + (size_t)kr * D + c * DJ;
+#pragma unroll
+    for (int j = 0; j < DJ / 4; j++) kn[j] = *reinterpret_cast<const f32x4*>(kp + 4 * j);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t r = kv0 + 4 * c + i, vr = r < kv_last ? r : kv_last;
+      const float* vp = vbase + (size_t)vr * D + n * DQ;
+#pragma unroll
+      for (int x = 0; x < DQ / 4; x++) vn[i][x] = *reinterpret_cast<const f32x4*>(vp + 4 * x);
+    }
+  };
+  if (wave < n_tiles) load_tile(wave);
+  for (uint32_t tile = wave; tile < n_tiles; tile += NW) {
+    const uint32_t kv0 = tile * 16;
+    f32x4 kf[DJ / 4], vf[4][DQ / 4];
+#pragma unroll
+    for (int j = 0; j < DJ / 4; j++) kf[j] = kn[j];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int x = 0; x < DQ / 4; x++) vf[i][x] = vn[i][x];
+    if (tile + NW < n_tiles) load_tile(tile + NW);   // the next tile's fragments are in flight while this one is computed
+    f32x4 st = (f32x4)(0.0f);
+#pragma unroll
+    for (int j = 0; j < DJ; j++) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j / 4][j % 4], qf[j], st, 0, 0, 0);
+    // st[i] = <q(token n), k(row kv0 + 4c + i)>; token n sees rows <= pos0 + tok
+    float sv[4], mx = kNegBig;
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      ok[i] = kv0 + 4 * c + i <= pos0 + tok;
+      sv[i] = ok[i] ? st[i] * scale : kNegBig;
+      mx = fmaxf(mx, sv[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - mn);
+    float pv[4], ps = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { pv[i] = ok[i] ? __expf(sv[i] - mn) : 0.0f; ps += pv[i]; }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = __builtin_fmaf(l_run, alpha, ps);
+    m_run = mn;
+#pragma unroll
+    for (int x = 0; x < DQ; x++) acc[x] = acc[x] * alpha;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int x = 0; x < DQ; x++) acc[x] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[i][x / 4][x % 4], pv[i], acc[x], 0, 0, 0);
+  }
+  // acc[x][i] = O^T[dim DQ (4c + i) + x][token n] of this wave's tiles
+  if (c == 0) { s_m[wave][n] = m_run; s_l[wave][n] = l_run; }
+#pragma unroll
+  for (int x = 0; x < DQ; x++) {
+    s_o[wave][n][DQ * (4 * c + 0) + x] = acc[x].x;
+    s_o[wave][n][DQ * (4 * c + 1) + x] = acc[x].y;
+    s_o[wave][n][DQ * (4 * c + 2) + x] = acc[x].z;
+    s_o[wave][n][DQ * (4 * c + 3) + x] = acc[x].w;
+  }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < 16u * D; e += NW * 64) {
+    const uint32_t t = e / D, dim = e % D;
+    if (tt * 16 + t >= m_tokens) continue;
+    float mn = s_m[0][t];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mn = fmaxf(mn, s_m[w][t]);
+    float lsum = 0.0f, a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float f = expf(s_m[w][t] - mn);
+      lsum += s_l[w][t] * f;
+      a += s_o[w][t][dim] * f;
+    }
+    const _Float16 o = (_Float16)(a * (1.0f / lsum));   // simd.rs:718-720: multiply by 1/sum
+    *reinterpret_cast<_Float16*>(xh_out + xh_offset(tt * 16 + t, head * D + dim)) = o;
+  }
+}
+
+template <int D>
+static hipError_t attn_pf_mfma_go(const float* q, const float* kc, const float* vc, uint32_t n_heads, uint32_t g, uint32_t max_seq, float scale,
+                                  uint32_t pos0, uint32_t m_tokens, uint8_t* xh_out, hipStream_t st) {
+  constexpr int NW = 8;   // (4 waves: 11.7 us per layer of a 128-token Llama-3-8B prompt, the last token tile's waves take two kv tiles each)
+  constexpr size_t lds = (size_t)(NW * 16 * (D + 4) + 2 * NW * 16) * 4;
+  static bool attr_set[64] = {};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_pf_mfma_kernel<D, NW>), (int)lds, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL((attn_pf_mfma_kernel<D, NW>), dim3(n_heads, (m_tokens + 15) / 16), dim3(NW * 64), lds, st, q, kc, vc, n_heads, g, max_seq, scale,
+                     pos0, m_tokens, xh_out);
+  return hipGetLastError();
+}
+
 // 4 waves per (kv head, token) workgroup: 8 and 16 waves measured slower on the 128-token Llama-3-8B prompt (4.79 / 5.07 vs
 // 4.74 ms per prompt pass) — the grid is already 1024 workgroups wide.
 template <int D, int G>
@@ -635,6 +780,11 @@ hipError_t attn_prefill_launch(const float* q, const float* kcache, const float*
                                hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || m_tokens == 0) return hipErrorInvalidValue;
   const uint32_t g = n_heads / n_kv;
+  static const bool valu = [] { const char* e = std::getenv("LGH_PF_ATTN_VALU"); return e && std::atoi(e) != 0; }();   // (A/B switch: the VALU kernel)
+  if (!valu && (head_dim == 128 || head_dim == 64)) {
+    return head_dim == 128 ? attn_pf_mfma_go<128>(q, kcache, vcache, n_heads, g, max_seq, scale, pos0, m_tokens, xh_out, st)
+                           : attn_pf_mfma_go<64>(q, kcache, vcache, n_heads, g, max_seq, scale, pos0, m_tokens, xh_out, st);
+  }
 #define LGH_ATTN_CASE(DD, GG) \
   if (head_dim == DD && g == GG) return attn_pf_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos0, m_tokens, xh_out, st);
   LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
