@@ -178,7 +178,7 @@ uint32_t mv_wave_cap(int dev_type);  // waves of the one workgroup per CU for th
 hipError_t mv_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 int mv_symbol(const MvLaunch& L);
 // int8-MFMA path (matvec_mfma.hip): Q4_K in the tile16 layout
-hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows);
+hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows, uint32_t force_tiles = 0);
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st);
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st);   // streaming-read probe
@@ -186,6 +186,7 @@ hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt
 uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out);
 int mvq_kernel_regs(uint32_t mask, bool flag);   // registers per lane of the instantiation for this format mask (-1: none)
 uint32_t mvq_format_mask(const MvLaunch& L);
+uint32_t mvq_tile_bytes(int dev_type);   // bytes of one 16-row x 256-element tile in the device layout of this type (0: not a tile16 type)
 hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h);
 hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st);
 // flow launch: the ops' workgroups side by side in one launch, ordered by hand-off counters (MvLaunch::flag_*)

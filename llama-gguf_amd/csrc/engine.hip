@@ -269,11 +269,41 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
     for (int s = 1; s < nseg; s++)
       if (specs[s].W[0]->type != specs[0].W[0]->type) wave_cap = std::min(wave_cap, 8u);
   }
+  // A fused launch over formats with different bytes per tile (the "_M" mixes: Q and K in Q4_K, V in Q6_K) is as long as its
+  // heaviest workgroup: the segments in the heavier format get fewer tiles per workgroup, as long as the launch still fits one
+  // workgroup per CU.  (Llama-3-8B QKV: 2 / 2 / 1 tiles -> 224 workgroups whose heaviest streams 2 x 2304 B per block instead
+  // of 192 whose heaviest streams 2 x 3392.)
+  uint32_t force_tiles[3] = {0, 0, 0};
+  if (mfma && nseg > 1 && !(c->d.flags & LGH_FLAG_PERSISTENT)) {   // (the persistent token kernel takes one geometry per op)
+    uint32_t R[3], Gs[3], tiles[3], w[3];
+    bool ok = true, mixed = false;
+    for (int s = 0; s < nseg && ok; s++) {
+      const DevWeight& W0 = *specs[s].W[0];
+      MvPlan p;
+      ok = mvq_plan(W0.k, W0.n, specs[s].npass, &p, launch_rows) == hipSuccess;
+      R[s] = p.rows_per_wg / 16; Gs[s] = p.G; tiles[s] = (W0.n + 15) / 16;
+      w[s] = mvq_tile_bytes(W0.type) * (uint32_t)specs[s].npass;
+      ok = ok && w[s] != 0;
+      mixed = mixed || w[s] != w[0];
+    }
+    for (int it = 0; ok && mixed && it < 32; it++) {
+      int h = 0;
+      for (int s = 1; s < nseg; s++)
+        if ((uint64_t)R[s] * w[s] > (uint64_t)R[h] * w[h]) h = s;
+      if (R[h] < 2 * Gs[h]) break;                                    // (a workgroup keeps at least one tile per row group)
+      uint32_t wgs = 0;
+      for (int s = 0; s < nseg; s++) { const uint32_t r = s == h ? R[h] - Gs[h] : R[s]; wgs += (tiles[s] + r - 1) / r; }
+      if (wgs > (uint32_t)kNumCU) break;
+      R[h] -= Gs[h];
+    }
+    if (ok && mixed)
+      for (int s = 0; s < nseg; s++) force_tiles[s] = R[s];
+  }
   for (int s = 0; s < nseg; s++) {
     const SegSpec& sp = specs[s];
     const DevWeight& W0 = *sp.W[0];
     MvPlan plan;
-    hipError_t pe = mfma ? mvq_plan(W0.k, W0.n, sp.npass, &plan, launch_rows)
+    hipError_t pe = mfma ? mvq_plan(W0.k, W0.n, sp.npass, &plan, launch_rows, force_tiles[s])
                          : mv_plan(W0.type, W0.k, W0.n, sp.npass, &plan, launch_rows, wave_cap);
     if (pe != hipSuccess)
       return fail(c, LGH_UNSUPPORTED, "no fused mat-vec plan for type " + std::to_string(W0.type) + " k=" + std::to_string(W0.k));

@@ -406,7 +406,9 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x3FFFu;
   const bool nrm = (geom >> 31) != 0;
   constexpr bool from_attn = ATTN;   // the input vector is merged from the attention's split partials (geom bit 30, host-checked)
-  const uint32_t S_nblk = geom2 & 0xFFFFu, Rg = geom2 >> 16;
+  const uint32_t S_nblk = geom2 & 0xFFFFu;
+  // tiles per workgroup and row group: launch-uniform for a single matrix, per segment in a fused launch (S_G is a power of two)
+  const uint32_t Rg = L.nseg > 1 ? S.rows_per_wg >> (4 + __builtin_ctz(S_G)) : geom2 >> 16;
   const uint32_t S_rpw = 16u * Rg * S_G;
   const uint32_t wg = bid - S_wgb;
 
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(kWaves * 64) mvq_flow_kernel(const MvLaunch* _
 // ------------------------------------------------------------------------------------------------
 // host: geometry and launch
 // ------------------------------------------------------------------------------------------------
-hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows) {
+hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32_t launch_rows, uint32_t force_tiles) {
   if (k == 0 || k % 256 || n_rows == 0 || npass < 1 || npass > 4) return hipErrorInvalidValue;
   const uint32_t nblk = k / 256, W = kWaves;
   uint32_t T = 1;
@@ -800,7 +802,7 @@ hipError_t mvq_plan(uint32_t k, uint32_t n_rows, int npass, MvPlan* plan, uint32
   const uint32_t tiles_launch = (launch_rows + 15) / 16;
   // tiles per workgroup: one workgroup per CU (two or three per CU, each with half / a third of the rows, measured the same
   // to 1 %: 15.5 / 15.6 / 15.7 us for the Llama-3-8B gate-up launch — a launch is bound by its fixed costs, not by waves in flight)
-  uint32_t R = (tiles_launch + kNumCU - 1) / kNumCU;
+  uint32_t R = force_tiles ? force_tiles : (tiles_launch + kNumCU - 1) / kNumCU;   // (force_tiles: the engine balances mixed-format launches)
   R = (R + G - 1) / G * G;
   const uint32_t threads = T * G * 64;
   const uint32_t rmax = threads / 16 / G * G;         // the epilogue gives every row (pair) a thread
@@ -842,7 +844,9 @@ uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp*
   uint32_t mask = 0;
   for (int i = 0; i < L.nseg; i++) {   // the launch-uniform geometry travels as scalars
     const MvSeg& Si = L.seg[i];
-    if (Si.T != S0.T || Si.G != S0.G || Si.units != S0.units || Si.nblk != S0.nblk || Si.rows_per_wg != S0.rows_per_wg ||
+    // (rows per workgroup may differ between the segments of one launch: a segment in a format with more bytes per tile
+    // gets fewer tiles per workgroup; the kernel reads it per segment)
+    if (Si.T != S0.T || Si.G != S0.G || Si.units != S0.units || Si.nblk != S0.nblk || Si.rows_per_wg % (16 * S0.G) ||
         (i > 0 && Si.wg_begin >= 0xFFFFu))
       return 0;
     const int f = fmt_of_dev_type(Si.type);
@@ -908,6 +912,11 @@ int mvq_kernel_regs(uint32_t mask, bool flag) {
 #undef LGH_MVQ_RCASE
   if (hipFuncGetAttributes(&a, fn) != hipSuccess) return -1;
   return a.numRegs;
+}
+
+uint32_t mvq_tile_bytes(int dev_type) {
+  const int f = fmt_of_dev_type(dev_type);
+  return f < 0 ? 0u : fmt_tile_bytes(f);
 }
 
 uint32_t mvq_format_mask(const MvLaunch& L) {
