@@ -341,9 +341,17 @@ def run_pipeline(args, pkg):
         vocab = stage.VOCAB
         red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], dtype=torch.float64))
     else:
+        # LGH_PP_ONE_GPU=1: correctness rehearsal of the multi-process path on a box with ONE GPU — every rank on device 0, hops
+        # staged through host memory over gloo (pipeline.HostStagedComm).  The line it prints says so; it is not a measurement.
+        one_gpu = os.environ.get("LGH_PP_ONE_GPU", "") not in ("", "0")
+        if one_gpu:
+            local = 0
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         sync = torch.cuda.synchronize
         max_seq = max(512, args.prompt + W + reps * K + min(args.profile_steps, 8) + 16)
         cfg = pkg.make_config(args.model, max_seq_len=max_seq)
@@ -353,8 +361,10 @@ def run_pipeline(args, pkg):
                                              attn_direct=args.attn_direct, attn_merge=args.attn_merge, flags=args.flags)
         stage = pkg.pipeline.HipStage(eng, torch, dev)
         vocab = cfg.vocab_size
-        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(torch.tensor([v], device=dev, dtype=torch.float64))
-    dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.TorchComm(dist))
+        red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(
+            torch.tensor([v], device="cpu" if one_gpu else dev, dtype=torch.float64))
+    staged = (not fake) and one_gpu
+    dec = pkg.pipeline.PipelineDecoder(stage, rank, world, pkg.pipeline.HostStagedComm(dist) if staged else pkg.pipeline.TorchComm(dist))
     prompt = prompt_tokens(args.prompt, vocab)
     prefill = None
     if not fake:
@@ -409,7 +419,8 @@ def run_pipeline(args, pkg):
             "value": round(tok_s, 2), "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "none (protocol rehearsal)" if fake else DTYPE_LABEL,
-            "data": "fake stage on CPU: launcher + hop protocol rehearsal, NOT a measurement" if fake else "synthetic",
+            "data": "fake stage on CPU: launcher + hop protocol rehearsal, NOT a measurement" if fake
+                    else "synthetic; every rank on ONE device, hops staged through the host: protocol rehearsal, NOT a measurement" if staged else "synthetic",
             "repetitions": {"n": len(rep_s), "ms_per_step": [round(1e3 * r / K, 4) for r in rep_s],
                             "min_ms_per_step": round(1e3 * min(rep_s) / K, 4), "best_value": round(K / min(rep_s), 2)},
             "config": {"workload": f"{name} single-stream greedy decode, kv_len {kv0 + 1}..{kv1}",

@@ -41,6 +41,24 @@ class TorchComm:
         self.dist.recv(tensor, src)
 
 
+class HostStagedComm:
+    """Rehearsal transport: device tensors hop through host memory over a CPU backend (gloo has no device send/recv).  Used to
+    run the multi-process protocol with REAL stage engines on a box with one GPU (every rank on device 0; RCCL refuses two ranks
+    on one device): same HipStage, same PipelineDecoder calls, but a host round trip per hop — a correctness rehearsal, never a
+    measurement."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def send(self, tensor, dst: int) -> None:
+        self.dist.send(tensor.cpu(), dst)             # (.cpu() waits for the stage's kernels on the current stream)
+
+    def recv(self, tensor, src: int) -> None:
+        host = tensor.cpu()
+        self.dist.recv(host, src)
+        tensor.copy_(host)                            # enqueued on the current stream, ahead of the stage's next kernels
+
+
 class PipelineDecoder:
     """Greedy single-stream decode over `world` stages.
 
@@ -162,8 +180,14 @@ class HipStage:
         self.engine = engine
         self.hidden = torch.as_tensor(DevicePtrTensor(engine.stage_hidden_ptr(), engine.hidden_size), device=device)
         self.token_buf = torch.zeros(1, dtype=torch.int32, device=device)
-        # kernels and the RCCL hop are ordered on torch's current stream
-        engine.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        # Kernels and the hop must be ordered on ONE stream.  torch's default stream has the handle 0, which lgh_set_stream reads
+        # as "the engine's own stream" — a non-blocking stream nothing in torch orders against, so a recv could land while the
+        # stage's kernels were still reading the vector (found by the one-GPU multi-process rehearsal, tests/test_gpu_model.py).
+        # The stage therefore makes a stream of its own current for torch (RCCL orders send/recv against the current stream)
+        # and hands that stream to the engine.
+        self.stream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(self.stream)
+        engine.set_stream(self.stream.cuda_stream)
         # batched prompt path (lgh_stage_prefill_batch): a [128][hidden] f32 block per hop instead of one vector per token
         self.block_tokens = 0
         if engine.prefill_is_batched():

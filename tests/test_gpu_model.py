@@ -350,6 +350,48 @@ def test_stage_contexts_decode_correctly_in_a_fresh_process():
         assert out and out[-1].startswith("rep 0") and out[-1].endswith("max|d|=0.000e+00"), out
 
 
+@pytest.mark.parametrize("name,layers,mix,world,batched", [("test-dense-d128", 3, "Q4_K_M", 2, False), ("test-dense-d128", 3, "Q4_K_M", 3, True),
+                                                          ("llama-3-8b", 4, "Q4_K_M", 2, True)])
+def test_multi_process_pipeline_rehearsal_on_one_gpu(pkg, name, layers, mix, world, batched):
+    """The multi-process layer pipeline with REAL stage engines: `world` ranks, each a fresh process holding its layer range
+    on device 0 (RCCL refuses two ranks on one device, so the hidden vector and the fed-back token hop through the host over
+    gloo: pipeline.HostStagedComm — same HipStage, same PipelineDecoder.prefill / decode_device calls as a run on `world`
+    GPUs).  The greedy tokens must equal the single-context decode of the same model token for token (per-token prompt: the
+    hidden vector crosses the boundary as f32, bit-exact; batched prompt blocks: the same f16 GEMM path on both sides)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_prompt, steps = 40, 24
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tools", "pp_rehearse.py"), name, str(layers), mix, str(n_prompt),
+                                       str(steps)] + (["batched"] if batched else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    cfg = pkg.make_config(name, max_seq_len=n_prompt + steps + 16, num_layers=layers)
+    one = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=mix), cfg.max_seq_len)
+    try:
+        prompt = [(31 * i + 7) % cfg.vocab_size for i in range(n_prompt)]
+        if batched and one.prefill_is_batched():
+            one.forward_batch(prompt[:-1])
+        else:
+            for t in prompt[:-1]:
+                one.prefill_token(t)
+        want = one.decode_greedy(prompt[-1], steps + 4).tolist()
+        assert got["tokens"] == want and got["position"] == one.position()
+    finally:
+        one.close()
+
+
 class _PerExpert:
     """Hands the experts over one tensor at a time, as the reference's loader renames them
     (`blk.N.ffn_gate.E.weight`, src/model/loader.rs:1171-1173), optionally leaving some out."""
