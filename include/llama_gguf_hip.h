@@ -245,7 +245,9 @@ const char* lgh_last_error(const lgh_ctx* ctx);
 int lgh_get_stats(lgh_ctx* ctx, lgh_stats* out);
 /* on: run eagerly with hipEvent pairs around every launch and accumulate lgh_stats.k_* */
 int lgh_set_profiling(lgh_ctx* ctx, int on);
-/* Use an external HIP stream (e.g. torch's current stream) for all work; NULL = the context's own. */
+/* Use an external HIP stream for all work; NULL = the context's own (a non-blocking stream).  NB the handle of the legacy
+ * default stream IS NULL: a caller whose other work runs on the default stream (torch without an explicit stream) must create
+ * a stream, run that work on it and pass it here — otherwise nothing orders that work against the context's kernels. */
 int lgh_set_stream(lgh_ctx* ctx, void* hip_stream);
 void* lgh_get_stream(lgh_ctx* ctx);
 int lgh_synchronize(lgh_ctx* ctx);
