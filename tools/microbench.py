@@ -30,11 +30,17 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--only", default="")
     ap.add_argument("--two-streams", action="store_true", help="alternate launches between two unordered streams (overlap experiment)")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape TYPE:K:N:MODE (e.g. Q4_K:4096:16384:2); with --only-extra nothing else runs")
+    ap.add_argument("--only-extra", action="store_true")
     ap.add_argument("--copies", type=int, default=0, help="weight copies cycled through (0 = enough to stay cold; 1 = hot in the Infinity Cache)")
     args = ap.parse_args()
     pkg = graft.load_package()
     hb, syn = pkg.hip_backend, pkg.synth
-    for label, tname, k, n, mode in SHAPES:
+    shapes = [] if args.only_extra else list(SHAPES)
+    for spec in args.shape:
+        tname, k, n, mode = spec.split(":")
+        shapes.append((f"extra {tname} {k}->{n} mode {mode}", tname, int(k), int(n), int(mode)))
+    for label, tname, k, n, mode in shapes:
         if args.only and args.only not in label:
             continue
         t = syn.TYPE_IDS[tname]
