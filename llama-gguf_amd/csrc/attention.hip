@@ -22,6 +22,9 @@
 #include "device_utils.h"
 #include "xq.h"
 #include "prefill.h"
+#include "timeline.h"
+
+LGH_TL_DEFINE(attn)
 
 namespace lgh {
 
@@ -52,6 +55,7 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
   __shared__ float s_ml[NW][G][2];
   __shared__ float s_acc[NW][G][D];
+  LGH_TL_BEGIN(attn, lgh::TL_ATTN, n_splits);
 
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
       if (dim == 0) { coh_store<FUSE>(&part_ml[(pbase + g) * 2], mn); coh_store<FUSE>(&part_ml[(pbase + g) * 2 + 1], lsum); }
     }
   }
+  LGH_TL_END();
   if constexpr (FUSE) {
     __shared__ unsigned s_last;
     __shared__ float s_f[G][64];
@@ -514,6 +519,7 @@ __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restri
                                                            float* __restrict__ out, uint8_t* __restrict__ xq_out) {
   __shared__ float s_f[64];
   __shared__ float s_linv;
+  LGH_TL_BEGIN(attn, lgh::TL_COMBINE, n_splits);
   const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
   const size_t p0 = (size_t)kvh * n_splits * g_per_kv + g;   // split s lives at p0 + s * g_per_kv
   // every partial this thread will need is requested up front (one dim per thread: blockDim == head_dim <= 128), so the
@@ -543,6 +549,7 @@ __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restri
     out[(size_t)h * head_dim + dim] = o;
     if (xq_out) xq_store_chunk(xq_out, (h * head_dim + dim) >> 4, o);   // wo's input as XQ records (head_dim % 16 == 0)
   }
+  LGH_TL_END();
 }
 
 template <int D, int G>

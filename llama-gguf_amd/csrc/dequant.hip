@@ -9,6 +9,9 @@
 #include "device_utils.h"
 #include "xq.h"
 #include "prefill.h"
+#include "timeline.h"
+
+LGH_TL_DEFINE(deq)
 
 namespace lgh {
 
@@ -153,6 +156,7 @@ hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t
 __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __restrict__ table, const int* token,
                                                     float* __restrict__ dst, uint32_t hidden, int* state,
                                                     uint8_t* __restrict__ xq, const float* __restrict__ xq_nw, float* __restrict__ xq_ssq, int bump_epoch) {
+  LGH_TL_BEGIN(deq, lgh::TL_EMBED, hidden);
   if (state && blockIdx.x == 0 && threadIdx.x == 0) {
     int p = state[ST_NEXT];
     state[ST_POS] = p;
@@ -167,6 +171,7 @@ __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __r
     // the first layer's QKV is an int8-MFMA consumer: leave its input as XQ records too (hidden % 256 == 0, host-checked)
     if (xq) xq_store_chunk(xq, i >> 4, xq_nw ? v * xq_nw[i] : v, xq_ssq, v);
   }
+  LGH_TL_END();
 }
 
 hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,

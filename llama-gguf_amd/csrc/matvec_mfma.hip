@@ -29,6 +29,9 @@
 #include "xq.h"
 #include "mvq_core.h"
 #include "handoff.h"
+#include "timeline.h"
+
+LGH_TL_DEFINE(mvq)
 
 namespace lgh {
 
@@ -677,7 +680,9 @@ template <uint32_t MASK, bool ATTN = false>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
+  LGH_TL_BEGIN(mvq, lgh::TL_MVQ, geom2);
   mvq_body<MASK, false, ATTN, false>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+  LGH_TL_END();
 }
 
 // Flag-ordered launches (handoff.h) run BESIDE their producer, two workgroups to a CU.  A consumer that waits on flags must

@@ -1,6 +1,9 @@
 // misc.hip — small decode-path kernels: standalone RMSNorm / RoPE / SiLU*mul (per-op surface and
 // fallbacks for shapes the fused epilogues do not cover), device arg-max, MoE router.
 #include "device_utils.h"
+#include "timeline.h"
+
+LGH_TL_DEFINE(misc)
 
 namespace lgh {
 
@@ -191,14 +194,17 @@ constexpr int kArgmaxParts = 64;
 __global__ void __launch_bounds__(256) argmax_stage1(const float* __restrict__ v, uint32_t n, float* pv, int* pi) {
   __shared__ float sv[4];
   __shared__ int si[4];
+  LGH_TL_BEGIN(misc, lgh::TL_ARGMAX1, n);
   float bv = -INFINITY;
   int bi = -1;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) amax_merge(bv, bi, v[i], (int)i);
   amax_block_reduce(bv, bi, sv, si);
   if (threadIdx.x == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; }
+  LGH_TL_END();
 }
 
 __global__ void __launch_bounds__(64) argmax_stage2(const float* pv, const int* pi, int nparts, int* state, int* out_token) {
+  LGH_TL_BEGIN(misc, lgh::TL_ARGMAX2, (unsigned)nparts);
   float bv = -INFINITY;
   int bi = -1;
   for (int i = threadIdx.x; i < nparts; i += 64) amax_merge(bv, bi, pv[i], pi[i]);
@@ -213,6 +219,7 @@ __global__ void __launch_bounds__(64) argmax_stage2(const float* pv, const int* 
     if (state) { state[ST_ARGMAX] = bi; state[ST_TOKEN] = bi; }  // feed the token back on device
     if (out_token) out_token[state ? state[ST_POS] : 0] = bi;      // token log, indexed by position
   }
+  LGH_TL_END();
 }
 
 hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,

@@ -19,6 +19,15 @@ extern "C" int lgh_debug_pf_stamps(unsigned long long* out, size_t n) { return l
 extern "C" int lgh_debug_pt_stamps(unsigned long long* out, size_t n) { return lgh::ptok_read_stamps(out, n) == hipSuccess ? 0 : 10; }
 namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); hipError_t mvq_spans(unsigned long long* host, int reset); }
 #include <cstdio>
+#include "timeline.h"
+namespace lgh { hipError_t tl_read_mvq(void*); hipError_t tl_read_attn(void*); hipError_t tl_read_deq(void*); hipError_t tl_read_misc(void*); }
+// the per-node timeline buffers of the four translation units on the decode path (timeline.h), `which` = 0..3;
+// out: sizeof(TlBuf) bytes.  Returns the buffer size when out == nullptr.
+extern "C" long long lgh_debug_timeline(int which, void* out) {
+  if (!out) return (long long)sizeof(lgh::TlBuf);
+  hipError_t e = which == 0 ? lgh::tl_read_mvq(out) : which == 1 ? lgh::tl_read_attn(out) : which == 2 ? lgh::tl_read_deq(out) : lgh::tl_read_misc(out);
+  return e == hipSuccess ? 0 : -1;
+}
 #endif
 
 namespace {
