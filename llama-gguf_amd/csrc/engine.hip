@@ -256,7 +256,7 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
   L.norm_w = norm_w;
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
-  L.dbg_slot = g_launch_seq++ & 1023u;   // (span stamps use the low 6 bits, the timeline all 10)
+  L.dbg_slot = g_launch_seq++ & 63u;
   L.flag_wait_first = L.flag_sig_first = kFlagNone;
   wg = 0; threads = 0; alg = 0;
   uint32_t launch_rows = 0;

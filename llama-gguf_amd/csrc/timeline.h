@@ -18,6 +18,8 @@ constexpr unsigned kTlSlots = 1024, kTlWg = 320;
 enum TlKind : unsigned { TL_EMBED = 1, TL_MVQ = 2, TL_ATTN = 3, TL_COMBINE = 4, TL_ARGMAX1 = 5, TL_ARGMAX2 = 6, TL_ADVANCE = 7, TL_XQ = 8, TL_MV = 9, TL_OTHER = 10 };
 struct TlBuf {
   unsigned long long t[kTlSlots][kTlWg][2];
+  unsigned long long clk[kTlSlots][kTlWg][2];   // s_memtime (shader clock) at the same two points: the workgroup's clock = dclk / dt
+  unsigned xcc[kTlSlots][kTlWg];                // HW_REG_XCC_ID of the workgroup's CU
   unsigned long long packet[kTlSlots];
   unsigned kind[kTlSlots], grid[kTlSlots], aux[kTlSlots], pad[kTlSlots];
 };
@@ -34,6 +36,8 @@ struct TlBuf {
   lgh::TlBuf& tl_buf_ = lgh::g_tl_##NAME;                                                         \
   if (tl_on_) {                                                                                   \
     tl_buf_.t[tl_slot_][blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();                        \
+    tl_buf_.clk[tl_slot_][blockIdx.x][0] = __builtin_amdgcn_s_memtime();                          \
+    tl_buf_.xcc[tl_slot_][blockIdx.x] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); /* HW_REG_XCC_ID, all bits */ \
     if (blockIdx.x == 0) { tl_buf_.packet[tl_slot_] = tl_dp_; tl_buf_.kind[tl_slot_] = (KIND); tl_buf_.grid[tl_slot_] = gridDim.x; tl_buf_.aux[tl_slot_] = (AUX); } \
   }
 // the same with the slot given by the caller (a kernel that cannot spare the two user SGPRs of the dispatch pointer)
@@ -43,11 +47,16 @@ struct TlBuf {
   lgh::TlBuf& tl_buf_ = lgh::g_tl_##NAME;                                                         \
   if (tl_on_) {                                                                                   \
     tl_buf_.t[tl_slot_][blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();                        \
+    tl_buf_.clk[tl_slot_][blockIdx.x][0] = __builtin_amdgcn_s_memtime();                          \
+    tl_buf_.xcc[tl_slot_][blockIdx.x] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  \
     if (blockIdx.x == 0) { tl_buf_.packet[tl_slot_] = 0; tl_buf_.kind[tl_slot_] = (KIND); tl_buf_.grid[tl_slot_] = gridDim.x; tl_buf_.aux[tl_slot_] = (AUX); } \
   }
 #define LGH_TL_END()                                                                              \
   do {                                                                                            \
-    if (tl_on_) tl_buf_.t[tl_slot_][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();           \
+    if (tl_on_) {                                                                                 \
+      tl_buf_.t[tl_slot_][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();                      \
+      tl_buf_.clk[tl_slot_][blockIdx.x][1] = __builtin_amdgcn_s_memtime();                        \
+    }                                                                                             \
   } while (0)
 #else
 #define LGH_TL_DEFINE(NAME)

@@ -27,7 +27,7 @@ SLOTS, WG = 1024, 320
 
 def read_nodes(lib):
     size = lib.lgh_debug_timeline(0, None)
-    assert size == SLOTS * WG * 16 + SLOTS * 8 + 4 * SLOTS * 4, size
+    assert size == SLOTS * WG * (16 + 16 + 4) + SLOTS * 8 + 4 * SLOTS * 4, size
     nodes = []
     for which in range(4):
         buf = (C.c_ubyte * size)()
@@ -35,6 +35,10 @@ def read_nodes(lib):
         raw = np.frombuffer(buf, dtype=np.uint8)
         t = raw[: SLOTS * WG * 16].view(np.uint64).reshape(SLOTS, WG, 2).astype(np.int64)
         o = SLOTS * WG * 16
+        clk = raw[o: o + SLOTS * WG * 16].view(np.uint64).reshape(SLOTS, WG, 2).astype(np.int64)
+        o += SLOTS * WG * 16
+        xcc = raw[o: o + SLOTS * WG * 4].view(np.uint32).reshape(SLOTS, WG)
+        o += SLOTS * WG * 4
         packet = raw[o: o + SLOTS * 8].view(np.uint64)
         o += SLOTS * 8
         kind = raw[o: o + SLOTS * 4].view(np.uint32); o += SLOTS * 4
@@ -48,7 +52,7 @@ def read_nodes(lib):
             if (t1 < t0).any() or t0.min() == 0:
                 continue   # a slot caught between two dispatches
             nodes.append(dict(kind=KIND.get(int(kind[s]), "?"), grid=int(grid[s]), aux=int(aux[s]), packet=int(packet[s]),
-                              t0=t0.copy(), t1=t1.copy()))
+                              t0=t0.copy(), t1=t1.copy(), c0=clk[s, :n, 0].copy(), c1=clk[s, :n, 1].copy(), xcc=(xcc[s, :n] & 0xF).copy()))
     nodes.sort(key=lambda d: d["t0"].min())
     return nodes
 
@@ -115,6 +119,35 @@ def main():
         layer_total += m["gap"] + m["span"]
         print(f"| {nm} | {m['gap']:.2f} | {m['ramp']:.2f} | {m['body']:.2f} | {m['tail']:.2f} | {m['span']:.2f} | {m['gap'] + m['span']:.2f} |")
     print(f"| layer | | | | | | {layer_total:.2f} |")
+    # where does the tail come from?  per-workgroup end times of the gate_up node of the printed layer, by XCD (blockIdx % 8)
+    # and by dispatch order (blockIdx / 8 = the order in which an XCD receives its workgroups)
+    # is the skew between XCDs stable?  per layer: the median end time of each physical XCD's workgroups in gate_up, and
+    # the shader clock each XCD ran at (d s_memtime / d s_memrealtime)
+    print("\n## gate_up per layer: median workgroup end (us since first start) by PHYSICAL XCD (HW_REG_XCC_ID), then shader clock GHz by XCD")
+    for (li, nm), d in zip(names, tok):
+        if nm == "gate_up" and li % 4 == 1:
+            base = d["t0"].min()
+            e = (d["t1"] - base) / 100.0
+            ghz = (d["c1"] - d["c0"]) / np.maximum(d["t1"] - d["t0"], 1) * 0.1
+            print(f"layer {li:2d}: end " + " ".join(f"{np.median(e[d['xcc'] == x]):6.2f}" if (d['xcc'] == x).any() else "   -  " for x in range(8))
+                  + "   clock " + " ".join(f"{np.median(ghz[d['xcc'] == x]):5.2f}" if (d['xcc'] == x).any() else "  -  " for x in range(8))
+                  + "   blockIdx%8 of XCD: " + " ".join(str(int(np.bincount((np.nonzero(d['xcc'] == x)[0] % 8), minlength=8).argmax())) if (d['xcc'] == x).any() else "-" for x in range(8)))
+    for want in ("gate_up", "wo"):
+        for (li, nm), d in zip(names, tok):
+            if li == a.layer and nm == want:
+                t0, t1 = d["t0"], d["t1"]
+                base = t0.min()
+                n = len(t0)
+                print(f"\n## {want} of layer {a.layer}: workgroup start / end (us since the first start) by XCD = blockIdx % 8\n| XCD | starts min..max | ends min / median / max |\n|---|---|---|")
+                for x in range(8):
+                    s0 = (t0[x::8] - base) / 100.0
+                    e0 = (t1[x::8] - base) / 100.0
+                    print(f"| {x} | {s0.min():.2f}..{s0.max():.2f} | {e0.min():.2f} / {np.median(e0):.2f} / {e0.max():.2f} |")
+                order = np.argsort(t1)
+                print("last 12 workgroups to end (blockIdx: end us, body us): " + ", ".join(f"{int(w)}: {(t1[w] - base) / 100.0:.2f}, {(t1[w] - t0[w]) / 100.0:.2f}" for w in order[-12:]))
+                print("first 12 workgroups to end: " + ", ".join(f"{int(w)}: {(t1[w] - base) / 100.0:.2f}" for w in order[:12]))
+                q = np.percentile((t1 - base) / 100.0, [0, 10, 25, 50, 75, 90, 95, 99, 100])
+                print("end-time percentiles 0/10/25/50/75/90/95/99/100: " + " ".join(f"{v:.2f}" for v in q))
     print("\n## the rest of the token (us)\n| node | grid | gap | ramp | body | tail | span |\n|---|---|---|---|---|---|---|")
     for r in rows:
         if r["layer"] < 0:
