@@ -110,7 +110,6 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=16, help="steps of the eager hipEvent pass (0 disables)")
     ap.add_argument("--attn-splits", type=int, default=0)
     ap.add_argument("--attn-direct", type=int, default=0, help="single-launch decode attention up to 64*n rows (0 = default, 255 = never)")
-    ap.add_argument("--attn-merge", type=int, default=0, help="8-split attention merged by the output projection up to 64*n rows (0 = default, 255 = never)")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of the K-step region (SURVEY.md §8d: 1 warm-up + 3, mean and min)")
     ap.add_argument("--flags", type=int, default=0, help="extra LGH_FLAG_* bits for the engine context")
     ap.add_argument("--inlib", action="store_true",
@@ -177,7 +176,7 @@ def run_single(args, pkg):
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
     eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct,
-                                         attn_merge=args.attn_merge, flags=args.flags)
+                                         flags=args.flags)
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
@@ -358,7 +357,7 @@ def run_pipeline(args, pkg):
         model = pkg.SynthModel(cfg, mix=args.mix)
         lo, hi = pkg.pipeline.split_layers(cfg.num_layers, world)[rank]
         eng = pkg.HipGpuInference.from_model(model, max_seq, device=local, layer_range=(lo, hi), attn_splits=args.attn_splits,
-                                             attn_direct=args.attn_direct, attn_merge=args.attn_merge, flags=args.flags)
+                                             attn_direct=args.attn_direct, flags=args.flags)
         stage = pkg.pipeline.HipStage(eng, torch, dev)
         vocab = cfg.vocab_size
         red = lambda v, op: (lambda t: (dist.all_reduce(t, op=op), float(t.item()))[1])(

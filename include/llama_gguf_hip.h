@@ -95,30 +95,18 @@ enum {
 
 enum {
   LGH_FLAG_NO_GRAPH = 1u << 0,       /* launch kernels eagerly instead of replaying a hipGraph */
-  LGH_FLAG_CHAIN_FFN = 1u << 1,      /* dense layers: wo -> gate/up -> down as ONE launch with grid barriers (resident workgroups) */
   LGH_FLAG_EXACT_PREFILL = 1u << 2,  /* lgh_prefill_batch feeds the tokens one by one (f32 throughout) instead of the batched f16 GEMM path */
-  LGH_FLAG_PERSISTENT = 1u << 3,     /* decode with the persistent token kernel (one launch per token, data-flow hand-offs between ops;
-                                        csrc/decode_persistent.hip) instead of the hipGraph of one launch per op.  Correct and tested, but
-                                        MEASURED SLOWER on MI355X (2.6 vs 1.6 ms per Llama-3-8B token), so it is opt-in */
-  LGH_FLAG_OVERLAP = 1u << 5,        /* dense layers whose matrices are in the matrix-core tile layouts run wo | gate-up | down | next QKV as
-                                        flag-ordered launches on TWO streams of the token graph: each is dispatched while its producer still runs,
-                                        puts its first weight tiles in flight and waits for hand-off counters instead of a kernel boundary
-                                        (csrc/handoff.h).  Same arithmetic, identical results; MEASURED SLOWER (541 vs 612 tokens/s on Llama-3-8B:
-                                        the graph's cross-stream edges and the write-through hand-off cost more than the boundaries) */
-  LGH_FLAG_FLOW_FFN = 1u << 6,       /* dense layers: wo | gate-up | down as ONE launch whose workgroups are split between the three ops and
-                                        ordered by the same counters (no kernel boundary, no grid barrier; mvq_flow_kernel).  Identical results;
-                                        measured 595 vs 612 tokens/s, opt-in */
-  LGH_FLAG_ATTN_FUSED = 1u << 7,     /* decode attention without the combine launch: every split stores its partial state write-through and
-                                        counts itself in; the split that arrives last merges them (identical results).  Measured 594 vs 607
-                                        tokens/s: the atomic round trip in every workgroup's tail costs more than the launch it saves; opt-in */
-  LGH_FLAG_KV_INT8 = 1u << 4,        /* KV cache in the reference's int8 format (QuantizedKVCache / KVCacheFormat::Int8, src/model/kv_quantized.rs;
-                                        `--kv-cache-type`): int8 rows + one f32 scale per (kv head, position), a quarter of the f32 cache */
+  LGH_FLAG_KV_INT8 = 1u << 4,        /* KV cache as the reference's QuantizedKVCache with KVCacheFormat::Int8 (src/model/kv_quantized.rs): int8
+                                        rows + one f32 scale per (kv head, position), a quarter of the f32 cache.  (Same as kv_cache_type =
+                                        LGH_KV_INT8; no CLI flag of the reference reaches this format, see kv_cache_type.) */
+  /* bits 1, 3, 5, 6, 7 and 24..31 selected the decode structures that round 2 built and measured SLOWER than the default graph of
+   * one launch per op (chained FFN with grid barriers, persistent token kernel, flag-ordered launches on two streams, flow
+   * launch, split attention merged by the last split / by the output projection: profiles/r02_decode_experiments.md).  They
+   * were removed in round 3; lgh_create answers LGH_UNSUPPORTED when one of them is set. */
+  LGH_FLAG_REMOVED_MASK = (1u << 1) | (1u << 3) | (1u << 5) | (1u << 6) | (1u << 7) | (0xFFu << 24),
   LGH_FLAG_ATTN_SPLITS_SHIFT = 8,    /* bits 8..15: KV splits per kv-head in decode attention (0 = auto) */
-  LGH_FLAG_ATTN_DIRECT_SHIFT = 16,   /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
+  LGH_FLAG_ATTN_DIRECT_SHIFT = 16    /* bits 16..23: contexts of up to 64 * n rows use the single-launch decode attention (one workgroup
                                         per kv head, no split + combine pair); 0 = the tuned default, 255 = never */
-  LGH_FLAG_ATTN_MERGE_SHIFT = 24     /* bits 24..31: contexts of up to 64 * n rows (beyond the single-launch range) run 8 KV splits per kv head
-                                        and the output projection's waves merge the split partials themselves (no combine launch);
-                                        0 = the default = never (measured slower than the combine launch, engine.hip), 255 = never */
 };
 
 typedef struct lgh_ctx lgh_ctx;
@@ -127,14 +115,14 @@ typedef struct lgh_ctx lgh_ctx;
 enum {
   LGH_K_EMBED = 0, LGH_K_QKV = 1, LGH_K_ATTN = 2, LGH_K_ATTN_COMBINE = 3, LGH_K_WO = 4, LGH_K_GATEUP = 5,
   LGH_K_DOWN = 6, LGH_K_ROUTER = 7, LGH_K_OUTPUT = 8, LGH_K_ARGMAX = 9, LGH_K_MISC = 10,
-  LGH_K_TOKEN = 11,   /* the persistent token kernel: every mat-vec and attention op of a decode step in one launch */
+  LGH_K_TOKEN = 11,   /* (unused since round 3: was the persistent token kernel) */
   LGH_K_COUNT = 16
 };
 
 /* kernel SYMBOLS reported by lgh_get_stats (profiling mode): what `rocprofv3 --kernel-trace --stats` groups by.
  * LGH_SYM_MV_* are the instantiations of lgh::mv_kernel<MASK, MAXT> (the VALU dequant mat-vec, csrc/matvec.hip; MASK bits:
  * Q4_K 1, Q5_K 2, Q6_K 4, Q8_0 8, Q4_0 16; MAXT = the instantiation's thread cap).  LGH_SYM_MVQ_* are the instantiations of
- * lgh::mvq_kernel<MASK, ATTN> (the int8 matrix-core mat-vec; ATTN = true only for the output projection fed from attention partials, csrc/matvec_mfma.hip; ITS mask bits: Q4_K 1, Q6_K 2, Q5_K 4, Q8_0 8,
+ * lgh::mvq_kernel<MASK> (the int8 matrix-core mat-vec, csrc/matvec_mfma.hip; ITS mask bits: Q4_K 1, Q6_K 2, Q5_K 4, Q8_0 8,
  * Q4_0 16). */
 enum {
   LGH_SYM_MV_Q4K = 0,      /* lgh::mv_kernel<1u, 1024>  : every matrix of the launch Q4_K */
@@ -152,12 +140,12 @@ enum {
   LGH_SYM_ARGMAX = 12,     /* argmax_stage1 + argmax_stage2 (two launches, timed together) */
   LGH_SYM_ROUTER = 13,
   LGH_SYM_OTHER = 14,
-  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1u, false> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
-  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<2u, false> : ... every matrix Q6_K */
-  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u, false> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
-  LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u, false> / <6u, false> : Q5_K (and Q5_K + Q6_K) */
-  LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u, false> / <16u, false> : Q8_0 / Q4_0 */
-  LGH_SYM_PTOK = 20,       /* lgh::ptok_kernel<MASK, D, G> : the persistent token kernel (decode_persistent.hip) */
+  LGH_SYM_MVQ_Q4K = 15,    /* lgh::mvq_kernel<1u> : int8 matrix-core mat-vec, every matrix of the launch Q4_K */
+  LGH_SYM_MVQ_Q6K = 16,    /* lgh::mvq_kernel<2u> : ... every matrix Q6_K */
+  LGH_SYM_MVQ_MIXED = 17,  /* lgh::mvq_kernel<3u> : ... Q4_K and Q6_K matrices in one launch (fused QKV of Q4_K_M) */
+  LGH_SYM_MVQ_Q5K = 18,    /* lgh::mvq_kernel<4u> / <6u> : Q5_K (and Q5_K + Q6_K) */
+  LGH_SYM_MVQ_Q80_Q40 = 19, /* lgh::mvq_kernel<8u> / <16u> : Q8_0 / Q4_0 */
+  LGH_SYM_PTOK = 20,       /* (unused since round 3) */
   LGH_SYM_COUNT = 24
 };
 
@@ -181,9 +169,7 @@ typedef struct lgh_stats {
    * profiled token — the fixed cost every k_time_us / sym_time_us sample carries on top of the kernel itself */
   double event_bracket_us;
   uint64_t event_bracket_samples;
-  /* producer -> consumer launch pairs of one decode step that run side by side on two streams, ordered by hand-off
-   * counters instead of a kernel boundary (LGH_FLAG_OVERLAP / LGH_FLAG_FLOW_FFN; 0 otherwise and where no pair of launches fits on a CU) */
-  uint64_t overlapped_edges;
+  uint64_t overlapped_edges;         /* always 0 (reserved: belonged to the flag-ordered launches removed in round 3) */
 } lgh_stats;
 
 /* ---- lifecycle: replaces GpuOnlyInference::from_model (src/backend/cuda/gpu_only.rs:426-726) ---- */

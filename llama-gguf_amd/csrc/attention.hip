@@ -38,19 +38,11 @@ constexpr float kNegBig = -1e30f;
 // DIRECT: one workgroup of NW = 16 waves per kv head and no second kernel: the workgroup merges its waves and writes the
 // normalised output (f32 at part_acc, XQ records at part_ml when not null) itself.  It saves one launch floor per layer
 // but pulls a kv head's whole K/V through one CU, so it only pays below ~100 rows (engine.hip: kDirectAttnDefaultKv).
-// FUSE: no combine launch either, at any context length: every split stores its partial state write-through, drains, and
-// counts itself in on its kv head's arrival counter; the split that arrives LAST merges all of them — the arithmetic of
-// attn_combine_kernel, lane s of a wave owning split s, so the result is the same bits whoever arrives last — and writes
-// the normalised output and wo's XQ records.  One kernel boundary (~4.8 us per layer on Llama-3-8B) becomes one atomic
-// round trip plus the merge in the tail of this kernel.  The counter is reset by the merging workgroup: the next launch
-// that uses it starts after this one has ended.
-template <int D, int G, int NW, bool PF = false, bool DIRECT = false, bool FUSE = false>
+template <int D, int G, int NW, bool PF = false, bool DIRECT = false>
 __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
                                                            const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
-                                                           float* __restrict__ part_ml, float* __restrict__ part_acc,
-                                                           unsigned* __restrict__ arrive = nullptr, float* __restrict__ out = nullptr,
-                                                           uint8_t* __restrict__ xq_out = nullptr) {
+                                                           float* __restrict__ part_ml, float* __restrict__ part_acc) {
   constexpr int LPR = D / 4;       // lanes per row
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
   __shared__ float s_ml[NW][G][2];
@@ -172,71 +164,11 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
       const _Float16 o = (_Float16)(a * (1.0f / lsum));   // simd.rs:718-720: multiply by 1/sum
       *reinterpret_cast<_Float16*>(reinterpret_cast<uint8_t*>(part_acc) + xh_offset(blockIdx.y, (uint32_t)(pbase + g) * D + dim)) = o;
     } else {
-      coh_store<FUSE>(&part_acc[(pbase + g) * D + dim], a);
-      if (dim == 0) { coh_store<FUSE>(&part_ml[(pbase + g) * 2], mn); coh_store<FUSE>(&part_ml[(pbase + g) * 2 + 1], lsum); }
+      part_acc[(pbase + g) * D + dim] = a;
+      if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
     }
   }
   LGH_TL_END();
-  if constexpr (FUSE) {
-    __shared__ unsigned s_last;
-    __shared__ float s_f[G][64];
-    __shared__ float s_linv[G];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached the coherence point
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned old = __hip_atomic_fetch_add(arrive + kvh * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = old + 1 == n_splits;
-      if (old + 1 == n_splits) __hip_atomic_store(arrive + kvh * 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the merge of attn_combine_kernel for the G heads of this kv head; split s of head g lives at p0 + s * G + g
-    const size_t p0 = (size_t)kvh * n_splits * G;
-    constexpr int kPer = (G * D + NW * 64 - 1) / (NW * 64);   // output elements per thread
-    constexpr int kBatch = kPer < 2 ? kPer : 2;                 // ... merged kBatch at a time (32 partials each in flight)
-    auto pa_load = [&](uint32_t e, uint32_t sidx) {
-      return (sidx < n_splits && e < (uint32_t)(G * D)) ? coh_load<true>(part_acc + (p0 + (size_t)sidx * G + e / D) * D + e % D) : 0.0f;
-    };
-    float pa[kBatch][32];
-#pragma unroll
-    for (int b = 0; b < kBatch; b++)
-#pragma unroll
-      for (uint32_t sidx = 0; sidx < 32; sidx++) pa[b][sidx] = pa_load(threadIdx.x + b * NW * 64, sidx);
-    for (uint32_t g = wave; g < (uint32_t)G; g += NW) {   // lane s owns split s
-      const bool ok = lane < n_splits;
-      const float m = ok ? coh_load<true>(part_ml + (p0 + (size_t)lane * G + g) * 2) : kNegBig;
-      const float l = ok ? coh_load<true>(part_ml + (p0 + (size_t)lane * G + g) * 2 + 1) : 0.0f;
-      const float mn = wave_max(m);
-      const float f = expf(m - mn);
-      const float lsum = wave_sum(l * f);
-      s_f[g][lane] = f;
-      if (lane == 0) s_linv[g] = 1.0f / lsum;  // simd.rs:718-720: multiply by 1/sum
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b0 = 0; b0 < kPer; b0 += kBatch) {
-      if (b0 > 0) {
-#pragma unroll
-        for (int b = 0; b < kBatch; b++)
-#pragma unroll
-          for (uint32_t sidx = 0; sidx < 32; sidx++) pa[b][sidx] = pa_load(threadIdx.x + (b0 + b) * NW * 64, sidx);
-      }
-#pragma unroll
-      for (int b = 0; b < kBatch; b++) {
-        const uint32_t e = threadIdx.x + (b0 + b) * NW * 64;
-        if (e < (uint32_t)(G * D)) {
-          const uint32_t g = e / D;
-          float a = 0.0f;
-#pragma unroll
-          for (uint32_t sidx = 0; sidx < 32; sidx++) a += pa[b][sidx] * s_f[g][sidx];   // s_f of absent splits is exp(-1e30 - m) = 0
-          const float o = a * s_linv[g];
-          const uint32_t idx = (uint32_t)(kvh * G) * D + e;
-          out[idx] = o;
-          if (xq_out) xq_store_chunk(xq_out, idx >> 4, o);   // wo's input as XQ records (16 consecutive lanes = one chunk)
-        }
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -564,34 +496,6 @@ static hipError_t attn_go(const float* q, const float* kc, const float* vc, uint
     hipLaunchKernelGGL((attn_partial_kernel<D, G, 4>), dim3(n_kv * n_splits), dim3(256), 0, st, q, kc, vc, max_seq, scale, pos,
                        kv_len_fixed, n_splits, part_ml, part_acc);
   return hipGetLastError();
-}
-
-template <int D, int G>
-static hipError_t attn_fused_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale,
-                                const int* pos, uint32_t n_splits, float* part_ml, float* part_acc, unsigned* arrive, float* out,
-                                uint8_t* xq_out, hipStream_t st) {
-  if (max_seq >= 2048)
-    hipLaunchKernelGGL((attn_partial_kernel<D, G, 8, false, false, true>), dim3(n_kv * n_splits), dim3(512), 0, st, q, kc, vc, max_seq, scale, pos,
-                       0, n_splits, part_ml, part_acc, arrive, out, xq_out);
-  else
-    hipLaunchKernelGGL((attn_partial_kernel<D, G, 4, false, false, true>), dim3(n_kv * n_splits), dim3(256), 0, st, q, kc, vc, max_seq, scale, pos,
-                       0, n_splits, part_ml, part_acc, arrive, out, xq_out);
-  return hipGetLastError();
-}
-
-// split attention whose last-arriving split merges (no combine launch); `arrive`: 16 words per kv head, zero before the first use
-hipError_t attn_fused_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
-                             uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc,
-                             unsigned* arrive, float* out, uint8_t* xq_out, hipStream_t st) {
-  if (n_kv == 0 || n_heads % n_kv || !pos || !arrive || n_splits == 0 || n_splits > 32) return hipErrorInvalidValue;
-  const uint32_t g = n_heads / n_kv;
-#define LGH_ATTN_CASE(DD, GG) \
-  if (head_dim == DD && g == GG)  \
-    return attn_fused_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, arrive, out, xq_out, st);
-  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
-  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
-#undef LGH_ATTN_CASE
-  return hipErrorInvalidValue;
 }
 
 hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,

@@ -129,7 +129,6 @@ struct MvSeg {
   float* xq_ssq;             // ... xq_ssq[row / 16] = sum of out^2 over the chunk
 };
 
-constexpr uint32_t kFlagNone = 0xFFFFFFFFu;
 struct MvLaunch {
   int nseg;
   uint32_t k;
@@ -142,27 +141,11 @@ struct MvLaunch {
   const float* ssq_part;     // int8-MFMA kernel with do_norm: partial sums of x^2 left by the producer of x
   uint32_t n_ssq_part;
   uint32_t dbg_slot;         // diagnostic builds: launch sequence number mod 64 (span stamps)
-  // int8-MFMA kernel, optional: the input vector is the decode attention's output, taken straight from the split partials
-  // (attention.hip: part_ml [(kv head, split, g)][2] = m, l; part_acc [(kv head, split, g)][D]) — every wave merges the heads
-  // of its own k-slice and converts them to XQ in LDS, so no combine kernel runs between attention and the output projection
-  const float* attn_ml;
-  const float* attn_acc;
-  uint32_t attn_splits, attn_g, attn_dshift;   // splits per kv head, query heads per kv head, log2(head_dim)
-  // int8-MFMA kernel, optional (flag-ordered launches, handoff.h): this launch may run BESIDE the launch that produces its
-  // input vector (two streams, no kernel boundary between them) — it puts its first weight tiles in flight, then waits for
-  // the counters of the XQ records it needs; and / or beside its consumer — it publishes its output write-through and signals
-  unsigned* flag_sync;         // counters (nullptr: an ordinary launch)
-  const int* flag_epoch;       // device word: tokens run through the flag-ordered graph so far, this one included
-  uint32_t flag_wait_first;    // first counter of the input vector's records (kFlagNone: the input is ordered by a kernel boundary)
-  uint32_t flag_sig_first;     // first counter of segment 0's output records (kFlagNone: nobody waits by flag)
   MvSeg seg[3];
 };
 
-// chained int8-MFMA ops (one launch, grid barriers in between; matvec_mfma.hip)
-struct MvChainOp { uint32_t wbpack, geom, geom2, red_floats, lds_red_off, n_wg, pad0, pad1; };
-constexpr int kChainMaxOps = 4;
-constexpr int kChainSyncWords = 640;   // launch base, top, per-XCD counters and generations, error flag
-struct MvChainHost { MvLaunch op[kChainMaxOps]; MvChainOp geo[kChainMaxOps]; int nops; uint32_t mask, threads; size_t lds; };
+// launch-uniform geometry of one int8-MFMA launch as the kernel takes it (mvq_pack)
+struct MvGeom { uint32_t wbpack, geom, geom2, red_floats, lds_red_off, n_wg; };
 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (defined in the .hip files)
@@ -183,15 +166,9 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
 hipError_t repack_q4k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt, hipStream_t st);   // streaming-read probe
 // launch-uniform geometry of one int8-MFMA op, packed as the kernel takes it; returns the format mask (0 = not launchable)
-uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out);
-int mvq_kernel_regs(uint32_t mask, bool flag);   // registers per lane of the instantiation for this format mask (-1: none)
+uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvGeom* g, size_t* lds_out);
 uint32_t mvq_format_mask(const MvLaunch& L);
 uint32_t mvq_tile_bytes(int dev_type);   // bytes of one 16-row x 256-element tile in the device layout of this type (0: not a tile16 type)
-hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h);
-hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st);
-// flow launch: the ops' workgroups side by side in one launch, ordered by hand-off counters (MvLaunch::flag_*)
-hipError_t mvq_flow_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h);
-hipError_t mvq_flow_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, hipStream_t st);
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
 hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
@@ -204,7 +181,7 @@ hipError_t repack_launch(int src_type, const uint8_t* raw, uint8_t* dst, const u
 hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t n_elems, hipStream_t st);
 // dequantize row `*token` of a [vocab][hidden] table in its NATIVE GGUF layout into dst (embedding lookup)
 hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,
-                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st, int bump_epoch = 0);
+                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st);
 
 // misc kernels
 hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st);
@@ -217,7 +194,7 @@ hipError_t matmul_f32_launch(const float* a, const float* b, float* c, uint32_t 
 hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint32_t n, hipStream_t st);
 hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,
                          hipStream_t st);
-hipError_t advance_launch(int* state, hipStream_t st, int bump_epoch = 0);
+hipError_t advance_launch(int* state, hipStream_t st);
 hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
                              uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st, uint32_t n_tokens = 1);
 
@@ -225,10 +202,6 @@ hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, con
 hipError_t attn_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv,
                        uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, int kv_len_fixed,
                        uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
-// split attention whose last-arriving split merges the partials itself (no combine launch); `arrive`: 16 zeroed words per kv head
-hipError_t attn_fused_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
-                             uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc,
-                             unsigned* arrive, float* out, uint8_t* xq_out, hipStream_t st);
 hipError_t attn_direct_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
                               uint32_t max_seq, float scale, const int* pos, float* out, uint8_t* xq_out, hipStream_t st);
 bool attn_shape_has_fast_kernel(uint32_t head_dim, uint32_t group);
@@ -259,8 +232,6 @@ inline hipError_t lds_opt_in(const void* fn, int bytes, bool (&done)[64]) {
 }
 
 // device state block: [0] token, [1] current position, [2] next position, [3] last arg-max
-// [4] tokens run through a flag-ordered graph so far (the epoch of the hand-off counters, handoff.h); [5] 1 = the opener of the
-// token being enqueued bumps [4] (set by the host around a flag-ordered capture, read by embed / advance)
-enum { ST_TOKEN = 0, ST_POS = 1, ST_NEXT = 2, ST_ARGMAX = 3, ST_EPOCH = 4, ST_WORDS = 8 };
+enum { ST_TOKEN = 0, ST_POS = 1, ST_NEXT = 2, ST_ARGMAX = 3, ST_WORDS = 8 };
 
 }  // namespace lgh

@@ -155,13 +155,12 @@ hipError_t dequant_launch(int src_type, const uint8_t* raw, float* dst, uint64_t
 // token reads state[POS]; stream order makes the store visible).
 __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __restrict__ table, const int* token,
                                                     float* __restrict__ dst, uint32_t hidden, int* state,
-                                                    uint8_t* __restrict__ xq, const float* __restrict__ xq_nw, float* __restrict__ xq_ssq, int bump_epoch) {
+                                                    uint8_t* __restrict__ xq, const float* __restrict__ xq_nw, float* __restrict__ xq_ssq) {
   LGH_TL_BEGIN(deq, lgh::TL_EMBED, hidden);
   if (state && blockIdx.x == 0 && threadIdx.x == 0) {
     int p = state[ST_NEXT];
     state[ST_POS] = p;
     state[ST_NEXT] = p + 1;
-    if (bump_epoch) state[ST_EPOCH] += 1;   // a token of a flag-ordered graph: the hand-off counters' targets move on (handoff.h)
   }
   const uint64_t row = (uint64_t)(uint32_t)*token;
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -175,10 +174,10 @@ __global__ void __launch_bounds__(256) embed_kernel(int type, const uint8_t* __r
 }
 
 hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, float* dst, uint32_t hidden, int* state,
-                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st, int bump_epoch) {
+                        uint8_t* xq, const float* xq_nw, float* xq_ssq, hipStream_t st) {
   if (!blk_elems(src_type) || (xq && hidden % 256)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(embed_kernel, dim3((hidden + 255) / 256), dim3(256), 0, st, src_type, table, token, dst, hidden,
-                     state, xq, xq_nw, xq_ssq, bump_epoch);
+                     state, xq, xq_nw, xq_ssq);
   return hipGetLastError();
 }
 

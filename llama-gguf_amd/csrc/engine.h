@@ -5,7 +5,6 @@
 #include <vector>
 
 #include "common.h"
-#include "ptok.h"
 
 namespace lgh {
 
@@ -31,9 +30,6 @@ enum TokenMode { MODE_PREFILL = 0, MODE_FORWARD = 1, MODE_GREEDY = 2, MODE_COUNT
 // current contents; `tag` = the RMSNorm weights it was multiplied with (nullptr: none).
 struct XqBuf { const float* f32 = nullptr; uint8_t* xq = nullptr; float* ssq = nullptr; uint32_t k = 0; bool fresh = false; const float* tag = nullptr; };
 
-// one chained FFN launch (engine.hip: launch_ffn_chain): host copy of the descriptors + their device image
-struct ChainSlot { MvChainHost host; uint8_t* dev = nullptr; bool prepared = false, uploaded = false; };
-
 // scratch of the batched prompt path (prefill.hip), allocated at the first lgh_prefill_batch that uses it
 struct PfScratch {
   bool ready = false;
@@ -50,20 +46,6 @@ struct PfScratch {
 };
 
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
-
-// The persistent token kernel's program for one graph mode (decode_persistent.hip): built once at finalize.
-struct PtProg {
-  bool built = false, usable = false;
-  std::vector<PtHostOp> ops;
-  uint8_t* dev = nullptr;        // device image: PtOp[n], MvLaunch[n_mv], PtAttn[n_attn]
-  unsigned* sync = nullptr;      // epoch, error flag, hand-off counters (never reset: they only grow)
-  PtProgram P{};
-  uint32_t mask = 0;
-  size_t lds = 0;
-  uint64_t weight_bytes = 0;     // algorithmic bytes of the program's matrices + vectors (KV rows are added per position)
-  const float* first_nw = nullptr;   // norm weights the program's first op expects its input XQ image multiplied with
-  std::string why;               // why the program cannot be used (diagnostics)
-};
 
 }  // namespace lgh
 
@@ -92,10 +74,8 @@ struct lgh_ctx {
   bool finalized = false;
   bool profiling = false;
   std::string err;
-  hipGraphExec_t graph[lgh::MODE_COUNT][3] = {};   // [mode][attention variant: 0 split + combine, 1 single launch (short context), 2 split + merge in wo]
+  hipGraphExec_t graph[lgh::MODE_COUNT][2] = {};   // [mode][attention variant: 0 split + combine, 1 single launch (short context)]
   bool attn_direct = false;                        // variant of the token being enqueued (chosen by the host-side position)
-  bool attn_merge = false;                         // ... 8 splits, merged by the output projection's waves (no combine kernel)
-  uint32_t merge_attn_max_kv = 0, merge_splits = 8;
   uint32_t direct_attn_max_kv = 0;                 // contexts up to this many rows take the single-launch attention
   uint64_t graph_nodes = 0;
   // accounting
@@ -103,29 +83,7 @@ struct lgh_ctx {
   std::vector<lgh::ProfRec> prof;
   std::vector<void*> allocs;  // everything hipMalloc'ed by this context
   std::vector<lgh::XqBuf> xqs;
-  std::vector<lgh::ChainSlot> chains;          // [graph mode][layer]
-  unsigned* attn_arrive = nullptr;             // arrival counters of the split attention that merges itself (16 words per kv head)
-  bool attn_fuse = false;
-  std::vector<lgh::ChainSlot> flows;           // [graph mode][layer]: flow launches (wo | gate-up | down in one launch, hand-off counters)
-  bool flow_mode = false;
-  std::vector<lgh::ChainSlot*> chain_pending;  // descriptor uploads deferred past a stream capture
-  unsigned* chain_sync = nullptr;              // grid-barrier words of the chained launches
-  // flag-ordered graphs (handoff.h): two consecutive mat-vec launches of a layer run side by side on two streams, ordered by
-  // hand-off counters instead of a kernel boundary, so that the second one's weight tiles are in flight while the first finishes
-  bool flag_mode = false;                      // the context's graphs are captured that way
-  bool flagging = false;                       // ... and one is being captured right now
-  unsigned* flag_sync = nullptr;               // error word + counters
-  std::vector<uint32_t> flag_edges;            // per owned layer: overlapped edges (1: wo->gate-up, 2: gate-up->down, 4: down->next QKV)
-  std::vector<uint32_t> flag_cnt;              // per owned layer: first counter of wo's / gate-up's / down's output records (3 per layer)
-  hipStream_t stream2 = nullptr;               // the other stream of a flag-ordered capture
-  std::vector<hipEvent_t> flag_events;         // fork / join markers of the capture
-  size_t flag_ev_next = 0;
-  hipStream_t flag_origin = nullptr;           // the stream the token being enqueued started on
-  uint32_t flag_qkv_wait = lgh::kFlagNone;     // counters the next fused QKV launch waits for (the previous layer's down projection)
   lgh::PfScratch pf;
-  lgh::PtProg pt[lgh::MODE_COUNT];             // persistent token kernel, per graph mode
-  float* pt_part = nullptr;                    // attention split partials of the persistent kernel
-  uint32_t pt_s_max = 0, pt_rows_per_split = 64;
   float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 
@@ -153,12 +111,6 @@ struct SegSpec {
   const float* resid = nullptr;
   const float* bias = nullptr;
   const float* moe_w = nullptr;
-  // the input vector is the attention output, merged from split partials inside the kernel (MvLaunch::attn_*)
-  const float* attn_ml = nullptr;
-  const float* attn_acc = nullptr;
-  uint32_t attn_splits = 0;
-  // flag-ordered launch (MvLaunch::flag_*): first counters of the input's / the output's XQ records
-  uint32_t flag_wait_first = lgh::kFlagNone, flag_sig_first = lgh::kFlagNone;
 };
 
 int fail(lgh_ctx* c, int status, const std::string& msg);

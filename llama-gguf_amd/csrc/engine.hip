@@ -15,7 +15,6 @@
 //                                                            arg-max back on device
 //   reset() zero-fills every cache over PCIe (808-843)       O(1): position rewind
 #include "engine.h"
-#include "handoff.h"
 #include "prefill.h"
 #include "xq.h"
 
@@ -65,13 +64,6 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
 // otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
 // 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
 constexpr uint32_t kDirectAttnDefaultKv = 64;
-// Optional (flag bits 24..31): contexts up to 64 * n rows run the decode attention with 8 splits per kv head and let the output
-// projection's waves merge the split partials themselves (matvec_mfma.hip: mvq_gather_attn) — one graph node fewer per layer.
-// MEASURED SLOWER on Llama-3-8B at kv 134..270 (577 vs 612 tokens/s): every one of the 256 output-projection workgroups
-// repeats the merge of all 32 heads (80 extra load instructions per wave, +5 us per launch), which costs more than the
-// 4.98 us combine node it removes.  Off by default.
-constexpr uint32_t kMergeAttnDefaultKv = 0;
-
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
@@ -257,7 +249,6 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
   L.pos = c->state + ST_POS;
   L.rope_cs = c->rope_cs;
   L.dbg_slot = g_launch_seq++ & 63u;
-  L.flag_wait_first = L.flag_sig_first = kFlagNone;
   wg = 0; threads = 0; alg = 0;
   uint32_t launch_rows = 0;
   uint32_t wave_cap = 16;
@@ -274,7 +265,7 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
   // workgroup per CU.  (Llama-3-8B QKV: 2 / 2 / 1 tiles -> 224 workgroups whose heaviest streams 2 x 2304 B per block instead
   // of 192 whose heaviest streams 2 x 3392.)
   uint32_t force_tiles[3] = {0, 0, 0};
-  if (mfma && nseg > 1 && !(c->d.flags & LGH_FLAG_PERSISTENT)) {   // (the persistent token kernel takes one geometry per op)
+  if (mfma && nseg > 1) {
     uint32_t R[3], Gs[3], tiles[3], w[3];
     bool ok = true, mixed = false;
     for (int s = 0; s < nseg && ok; s++) {
@@ -325,11 +316,7 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
       if (mfma) {   // the input vector as XQ records: left by its producer, or converted here
         XqBuf* q = xq_get(c, sp.x[p], k);
         if (!q) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
-        if (sp.attn_acc) {   // merged from the attention's split partials inside the kernel: no image in memory at all
-          L.attn_ml = sp.attn_ml; L.attn_acc = sp.attn_acc; L.attn_splits = sp.attn_splits;
-          L.attn_g = c->d.num_heads / c->d.num_kv_heads;
-          L.attn_dshift = c->d.head_dim == 64 ? 6u : 7u;
-        } else if (!q->fresh || q->tag != norm_w) {
+        if (!q->fresh || q->tag != norm_w) {
           int rq = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)k * 4, [&] {
             return xq_quantize_launch(sp.x[p], norm_w, q->xq, norm_w ? q->ssq : nullptr, k, c->stream);
           });
@@ -341,11 +328,6 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
         if (norm_w) { L.ssq_part = q->ssq; L.n_ssq_part = k / 16; }
       }
       alg += W.bytes;
-    }
-    if (mfma && c->flagging && (sp.flag_wait_first != kFlagNone || sp.flag_sig_first != kFlagNone)) {
-      L.flag_sync = c->flag_sync;
-      L.flag_epoch = c->state + ST_EPOCH;
-      if (s == 0) { L.flag_wait_first = sp.flag_wait_first; L.flag_sig_first = sp.flag_sig_first; }
     }
     S.out = sp.out; S.out2 = sp.out2; S.resid = sp.resid; S.bias = sp.bias; S.moe_w = sp.moe_w;
     {  // XQ image of the output for the next consumer, where this epilogue can write one
@@ -399,48 +381,6 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
 }
 
-// ------------------------------------------------------------------------------------------------
-// Chained dense FFN block: wo (+residual) -> gate/up (SwiGLU) -> down (+residual) in ONE launch with grid barriers in
-// between (matvec_mfma.hip: mvq_chain_kernel).  The descriptors are static per (graph mode, layer): built at the first
-// enqueue, uploaded once — during a stream capture the upload is deferred until the capture has ended.
-// ------------------------------------------------------------------------------------------------
-static int launch_ffn_chain(lgh_ctx* c, int mode, uint32_t li, const SegSpec* specs, const float* const* norm_ws, const uint32_t* ks,
-                            const int* clss, int nops, bool flow = false) {
-  MvLaunch Ls[kChainMaxOps];
-  uint32_t wgs[kChainMaxOps], ths[kChainMaxOps];
-  uint64_t alg = 0;
-  for (int i = 0; i < nops; i++) {
-    uint64_t a = 0;
-    int rc = build_mv_group(c, specs + i, 1, norm_ws[i], ks[i], true, Ls[i], wgs[i], ths[i], a);
-    if (rc) return rc;
-    alg += a;
-  }
-  ChainSlot& slot = (flow ? c->flows : c->chains)[(size_t)mode * c->d.num_layers + li];
-  if (!slot.prepared) {
-    if ((flow ? mvq_flow_prepare(Ls, wgs, ths, nops, &slot.host) : mvq_chain_prepare(Ls, wgs, ths, nops, &slot.host)) != hipSuccess)
-      return fail(c, LGH_UNSUPPORTED, "FFN chain: unsupported geometry");
-    slot.prepared = true;
-    slot.uploaded = false;
-  }
-  if (!slot.uploaded) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(c->stream, &cs);
-    if (cs == hipStreamCaptureStatusNone) {
-      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(slot.dev, slot.host.op, sizeof(MvLaunch) * kChainMaxOps, hipMemcpyHostToDevice));
-      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(slot.dev + sizeof(MvLaunch) * kChainMaxOps, slot.host.geo, sizeof(MvChainOp) * kChainMaxOps, hipMemcpyHostToDevice));
-      slot.uploaded = true;
-    } else {
-      c->chain_pending.push_back(&slot);   // uploaded by capture_graph() right after hipStreamEndCapture
-    }
-  }
-  const MvLaunch* dev_ops = reinterpret_cast<const MvLaunch*>(slot.dev);
-  const MvChainOp* dev_geo = reinterpret_cast<const MvChainOp*>(slot.dev + sizeof(MvLaunch) * kChainMaxOps);
-  (void)clss;
-  return run_k(c, LGH_K_GATEUP, slot.host.mask == 1u ? LGH_SYM_MVQ_Q4K : LGH_SYM_MVQ_MIXED, alg, [&] {
-    return flow ? mvq_flow_launch(slot.host, dev_ops, dev_geo, c->stream) : mvq_chain_launch(slot.host, dev_ops, dev_geo, c->chain_sync, c->stream);
-  });
-}
-
 // Segments are independent (disjoint outputs), so a launch whose matrices live in different kernel families
 // (Q4_K on the matrix cores, the rest on the VALU kernel) is issued as one launch per family.
 int launch_mv(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k) {
@@ -489,19 +429,6 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
 }
 
 // ------------------------------------------------------------------------------------------------
-// flag-ordered capture (handoff.h): cross-stream edges of the graph being captured
-// ------------------------------------------------------------------------------------------------
-static hipStream_t flag_other(lgh_ctx* c, hipStream_t s) { return s == c->stream2 ? c->flag_origin : c->stream2; }
-
-// everything enqueued on `from` so far precedes whatever is enqueued on `to` from now on
-static int flag_edge(lgh_ctx* c, hipStream_t from, hipStream_t to) {
-  if (c->flag_ev_next >= c->flag_events.size()) return fail(c, LGH_OPERATION_FAILED, "flag-ordered capture: out of events");
-  hipEvent_t e = c->flag_events[c->flag_ev_next++];
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipEventRecord(e, from));
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamWaitEvent(to, e, 0));
-  return LGH_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // one transformer layer (TransformerLayer::forward serial-residual branch, layers.rs:1187-1244)
 // ------------------------------------------------------------------------------------------------
@@ -522,9 +449,6 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     sp[0].W[0] = &Lw.wq; sp[0].x[0] = c->hidden; sp[0].epi = EPI_ROPE_Q; sp[0].out = c->q; sp[0].bias = Lw.bq;
     sp[1].W[0] = &Lw.wk; sp[1].x[0] = c->hidden; sp[1].epi = kv8 ? EPI_ROPE_Q : EPI_ROPE_K; sp[1].out = kv8 ? k_new : Lw.kcache; sp[1].bias = Lw.bk;
     sp[2].W[0] = &Lw.wv; sp[2].x[0] = c->hidden; sp[2].epi = kv8 ? EPI_STORE : EPI_V_CACHE; sp[2].out = kv8 ? v_new : Lw.vcache; sp[2].bias = Lw.bv;
-    // flag-ordered: this launch runs beside the previous layer's down projection and waits for ITS records
-    for (int i = 0; i < 3; i++) sp[i].flag_wait_first = c->flag_qkv_wait;
-    c->flag_qkv_wait = kFlagNone;
     if ((rc = launch_mv(c, LGH_K_QKV, sp, 3, Lw.attn_norm, H))) return rc;
   } else {
     float* kt = c->kv_tmp;
@@ -546,7 +470,6 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) *
                             (d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4 : kv8 ? d.head_dim : d.head_dim * 4);
-  const bool merge = c->attn_merge && !c->attn_direct && mfma_type(Lw.wo.type);
   if (kv8) {
     // int8 rows + scales (kv_quantized.rs); the launch also quantizes and stores the current token's rows
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
@@ -578,24 +501,6 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
       return rc;
     if (qa) { qa->fresh = true; qa->tag = nullptr; }
     else xq_stale(c, c->attn_out);
-  } else if (merge) {
-    // few splits, merged by the output projection's own waves (MvLaunch::attn_*): no combine launch
-    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
-           return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
-                              c->state + ST_POS, 0, c->merge_splits, c->part_ml, c->part_acc, c->stream);
-         })))
-      return rc;
-    xq_stale(c, c->attn_out);
-  } else if (c->attn_fuse) {
-    // split attention, merged by whichever split arrives last: no combine launch
-    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
-    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
-           return attn_fused_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, c->state + ST_POS,
-                                    c->n_splits, c->part_ml, c->part_acc, c->attn_arrive, c->attn_out, qa ? qa->xq : nullptr, c->stream);
-         })))
-      return rc;
-    if (qa) { qa->fresh = true; qa->tag = nullptr; }
-    else xq_stale(c, c->attn_out);
   } else {
   if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_launch(c->q, Lw.kcache, Lw.vcache, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale,
@@ -615,88 +520,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   }
   // ---- h = x + wo(attn)   (layers.rs:700-701, 1201-1208)
   const bool ffn_mfma = Lw.moe() ? mfma_type(Lw.gate_exps.type) : mfma_type(Lw.gate.type);
-  auto q46 = [](int t) { return t == kDevQ4K_T16 || t == kDevQ6K_T16; };
-  if ((d.flags & LGH_FLAG_CHAIN_FFN) && !c->profiling && !Lw.moe() && q46(Lw.wo.type) && q46(Lw.gate.type) && Lw.gate.type == Lw.up.type &&
-      q46(Lw.down.type) && !Lw.bo && c->chain_sync) {
-    // wo -> gate/up -> down in one launch (resident workgroups, grid barriers instead of kernel boundaries)
-    SegSpec sp[3];
-    sp[0].W[0] = &Lw.wo; sp[0].x[0] = c->attn_out; sp[0].epi = EPI_RESID; sp[0].out = c->hidden; sp[0].resid = c->hidden;
-    sp[0].xq_next = 2; sp[0].xq_next_nw = Lw.ffn_norm;
-    sp[1].npass = 2; sp[1].W[0] = &Lw.gate; sp[1].W[1] = &Lw.up; sp[1].x[0] = sp[1].x[1] = c->hidden; sp[1].epi = EPI_SWIGLU;
-    sp[1].out = c->act; sp[1].xq_next = 1;
-    sp[2].W[0] = &Lw.down; sp[2].x[0] = c->act; sp[2].epi = EPI_RESID; sp[2].out = c->hidden; sp[2].resid = c->hidden;
-    sp[2].xq_next = next_mfma ? 2 : 0; sp[2].xq_next_nw = next_nw;
-    const float* nws[3] = {nullptr, Lw.ffn_norm, nullptr};
-    const uint32_t ks[3] = {Lw.wo.k, H, Lw.down.k};
-    const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
-    return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3);
-  }
-  uint32_t fe = c->flagging && !merge && li - c->l0 < c->flag_edges.size() ? c->flag_edges[li - c->l0] : 0u;
-  if (c->flow_mode && !(fe & 8u)) fe = 0;   // (flow launches and two-stream pairs are not mixed in one graph)
-  if (fe) {
-    // wo | gate-up | down | the next layer's QKV as flag-ordered launches on two streams (handoff.h).  Across an OVERLAPPED
-    // edge (bit 0: wo -> gate-up, bit 1: gate-up -> down, bit 2: down -> next QKV; chosen at finalize, where both launches
-    // fit on a CU together) the consumer goes to the other stream, is dispatched while its producer runs, has its first
-    // weight tiles in flight and then waits for the producer's records by counter.  The other stream must have caught up
-    // with everything BEFORE the producer (at most two of these launches are ever in flight): it has when the previous edge
-    // was overlapped too (it carries the producer's producer), otherwise an event edge is recorded in front of the producer.
-    // Across an edge that is not overlapped the consumer simply follows on the producer's stream.  Same kernels' arithmetic
-    // either way: the results are bit-identical to the single-stream graph (tests/test_gpu_model.py).
-    const uint32_t* cnt = &c->flag_cnt[(li - c->l0) * 3];
-    if (c->flow_mode && (fe & 8u)) {
-      // ONE launch for wo | gate-up | down: the three ops' workgroups side by side, ordered by the same counters (mvq_flow_kernel)
-      SegSpec sp[3];
-      sp[0].W[0] = &Lw.wo; sp[0].x[0] = c->attn_out; sp[0].epi = EPI_RESID; sp[0].out = c->hidden; sp[0].resid = c->hidden; sp[0].bias = Lw.bo;
-      sp[0].xq_next = 2; sp[0].xq_next_nw = Lw.ffn_norm; sp[0].flag_sig_first = cnt[0];
-      sp[1].npass = 2; sp[1].W[0] = &Lw.gate; sp[1].W[1] = &Lw.up; sp[1].x[0] = sp[1].x[1] = c->hidden; sp[1].epi = EPI_SWIGLU;
-      sp[1].out = c->act; sp[1].xq_next = 1; sp[1].flag_wait_first = cnt[0]; sp[1].flag_sig_first = cnt[1];
-      sp[2].W[0] = &Lw.down; sp[2].x[0] = c->act; sp[2].epi = EPI_RESID; sp[2].out = c->hidden; sp[2].resid = c->hidden;
-      sp[2].xq_next = next_mfma ? 2 : 0; sp[2].xq_next_nw = next_nw; sp[2].flag_wait_first = cnt[1];
-      const float* nws[3] = {nullptr, Lw.ffn_norm, nullptr};
-      const uint32_t ks[3] = {Lw.wo.k, H, Lw.down.k};
-      const int clss[3] = {LGH_K_WO, LGH_K_GATEUP, LGH_K_DOWN};
-      return launch_ffn_chain(c, mode, li, sp, nws, ks, clss, 3, true);
-    }
-    const bool e1 = fe & 1u, e2 = fe & 2u, e3 = fe & 4u;
-    hipStream_t cur = c->stream, oth = flag_other(c, cur);
-    // ---- wo
-    if (e1 && (rc = flag_edge(c, cur, oth))) return rc;          // the other stream catches up with the attention
-    SegSpec so;
-    so.W[0] = &Lw.wo; so.x[0] = c->attn_out; so.epi = EPI_RESID; so.out = c->hidden; so.resid = c->hidden; so.bias = Lw.bo;
-    so.xq_next = 2; so.xq_next_nw = Lw.ffn_norm; so.flag_sig_first = e1 ? cnt[0] : kFlagNone;
-    if ((rc = launch_mv(c, LGH_K_WO, &so, 1, nullptr, Lw.wo.k))) return rc;
-    // ---- gate/up
-    if (e1) std::swap(cur, oth);
-    else if (e2 && (rc = flag_edge(c, cur, oth))) return rc;     // ... with wo
-    c->stream = cur;
-    SegSpec sg;
-    sg.npass = 2; sg.W[0] = &Lw.gate; sg.W[1] = &Lw.up; sg.x[0] = sg.x[1] = c->hidden; sg.epi = EPI_SWIGLU; sg.out = c->act; sg.xq_next = 1;
-    sg.flag_wait_first = e1 ? cnt[0] : kFlagNone; sg.flag_sig_first = e2 ? cnt[1] : kFlagNone;
-    if ((rc = launch_mv(c, LGH_K_GATEUP, &sg, 1, Lw.ffn_norm, H))) return rc;
-    // ---- down
-    if (e2) std::swap(cur, oth);                                 // (e1: that stream carries wo; else the edge above)
-    else if (e3 && (rc = flag_edge(c, cur, oth))) return rc;     // ... with gate/up
-    c->stream = cur;
-    SegSpec sd;
-    sd.W[0] = &Lw.down; sd.x[0] = c->act; sd.epi = EPI_RESID; sd.out = c->hidden; sd.resid = c->hidden;
-    sd.xq_next = next_mfma ? 2 : 0; sd.xq_next_nw = next_nw;
-    sd.flag_wait_first = e2 ? cnt[1] : kFlagNone; sd.flag_sig_first = e3 ? cnt[2] : kFlagNone;
-    if ((rc = launch_mv(c, LGH_K_DOWN, &sd, 1, nullptr, Lw.down.k))) return rc;
-    // ---- the next layer continues on ...
-    if (e3) {
-      std::swap(cur, oth);                                       // ... the other stream, beside down (e2: it carries gate/up; else the edge above)
-      c->flag_qkv_wait = cnt[2];
-    }
-    c->stream = cur;
-    return LGH_OK;
-  }
-  if (merge) {
-    SegSpec sp;
-    sp.W[0] = &Lw.wo; sp.x[0] = c->attn_out; sp.epi = EPI_RESID; sp.out = c->hidden; sp.resid = c->hidden; sp.bias = Lw.bo;
-    sp.xq_next = ffn_mfma ? 2 : 0; sp.xq_next_nw = Lw.ffn_norm;
-    sp.attn_ml = c->part_ml; sp.attn_acc = c->part_acc; sp.attn_splits = c->merge_splits;
-    if ((rc = launch_mv(c, LGH_K_WO, &sp, 1, nullptr, Lw.wo.k))) return rc;
-  } else if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
+  if ((rc = linear_any(c, LGH_K_WO, Lw.wo, c->attn_out, c->hidden, nullptr, c->hidden, Lw.bo, ffn_mfma ? 2 : 0, Lw.ffn_norm))) return rc;
   if (c->profiling) {  // an EMPTY event bracket in mid-stream: what the measurement itself adds to every sample (at the
     // head of a token, on an idle stream, the same bracket reads differently from run to run)
     if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
@@ -767,234 +591,10 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   return LGH_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// The persistent token kernel's program (decode_persistent.hip): every mat-vec and attention op of a decode step of this
-// context, in order, with the hand-off counters between them.  Built once per graph mode at finalize (never during a
-// capture); the launch-per-op path stays behind it for everything the kernel is not built for (MoE layers, formats
-// outside the tile layouts, NeoX RoPE, odd head shapes) and behind LGH_FLAG_NO_PERSISTENT.
-// ------------------------------------------------------------------------------------------------
-static int ilog2(uint32_t v) { int s = 0; while ((1u << s) < v) s++; return s; }
-
-static int pt_build(lgh_ctx* c, int mode) {
-  PtProg& R = c->pt[mode];
-  if (R.built) return LGH_OK;
-  R.built = true;
-  R.usable = false;
-  const lgh_model_desc& d = c->d;
-  const uint32_t H = d.hidden_size, D = d.head_dim, NH = d.num_heads, NKV = d.num_kv_heads, G = NH / NKV;
-  auto no = [&](const std::string& why) { R.why = why; return LGH_OK; };
-  if (!(d.flags & LGH_FLAG_PERSISTENT) || (d.flags & (LGH_FLAG_CHAIN_FFN | LGH_FLAG_KV_INT8))) return no("not requested (LGH_FLAG_PERSISTENT)");
-  int cus = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || cus < kNumCU) return no("device has fewer than 256 CUs");
-  if (H % 256 || (NH * D) % 256 || d.use_neox_rope || c->l0 >= c->l1) return no("shape");
-  const bool head = c->last && mode != MODE_PREFILL;
-  if (head && !mfma_type(c->output.type)) return no("output projection is not in a tile layout");
-  for (uint32_t li = c->l0; li < c->l1; li++) {
-    const LayerW& Lw = c->layers[li];
-    if (Lw.moe()) return no("MoE layer");
-    for (const DevWeight* W : {&Lw.wq, &Lw.wk, &Lw.wv, &Lw.wo, &Lw.gate, &Lw.up, &Lw.down})
-      if (!mfma_type(W->type) || W->n % 16) return no("a matrix is not in a tile layout");
-    if (Lw.gate.type != Lw.up.type || d.intermediate_size % 256) return no("FFN shape");
-  }
-  // ---- ops
-  std::vector<PtHostOp>& ops = R.ops;
-  ops.clear();
-  uint32_t ncnt = 0;
-  uint64_t bytes = 0;
-  bool bad = false;
-  auto add_mv = [&](const SegSpec* sp, int nseg, const float* norm_w, uint32_t k, uint32_t in_kind, uint32_t in_cnt) -> PtHostOp* {
-    PtHostOp h{};
-    uint32_t wg = 0, threads = 0;
-    uint64_t alg = 0;
-    if (build_mv_group(c, sp, nseg, norm_w, k, true, h.mv, wg, threads, alg)) { bad = true; return nullptr; }
-    MvChainOp g;
-    size_t lds = 0;
-    if (!mvq_pack(h.mv, wg, threads, &g, &lds) || threads != (uint32_t)kPtWaves * 64 || wg > (uint32_t)kNumCU || h.mv.seg[0].units > 64) { bad = true; return nullptr; }
-    for (int s = 0; s < nseg; s++)
-      for (int p = 0; p < h.mv.seg[s].npass; p++)
-        if (h.mv.seg[s].pass[p].sel) { bad = true; return nullptr; }
-    h.op.kind = PT_MV;
-    h.op.n_wg = wg;
-    h.op.wbpack = g.wbpack; h.op.geom = g.geom; h.op.geom2 = g.geom2; h.op.red_floats = g.red_floats; h.op.lds_red_off = g.lds_red_off;
-    h.op.in_kind = in_kind;
-    h.op.in_cnt = in_cnt;
-    for (int s = 0; s < 3; s++) { h.op.out_cnt[s] = kPtNone; h.op.out_shift[s] = 0; }
-    h.op.next_mv = kPtNone;
-    h.op.attn = kPtNone;
-    h.threads = threads;
-    h.alg_bytes = alg;
-    bytes += alg;
-    ops.push_back(h);
-    return &ops.back();
-  };
-  for (auto& q : c->xqs) q.fresh = false;
-  XqBuf* qh = xq_get(c, c->hidden, H);
-  XqBuf* qa = xq_get(c, c->attn_out, NH * D);
-  if (!qh || !qa) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
-  R.first_nw = c->layers[c->l0].attn_norm;
-  qh->fresh = true;            // left by the embedding kernel (first stage) or converted in front of the launch (other stages)
-  qh->tag = R.first_nw;
-  uint32_t in_kind = PT_IN_READY, in_cnt = 0;
-  const float scale = 1.0f / std::sqrt((float)D);   // layers.rs:374
-  for (uint32_t li = c->l0; li < c->l1 && !bad; li++) {
-    LayerW& Lw = c->layers[li];
-    const float* next_nw = nullptr;
-    bool next_mfma = false;
-    if (li + 1 < c->l1) { next_nw = c->layers[li + 1].attn_norm; next_mfma = true; }
-    else if (head) { next_nw = c->output_norm; next_mfma = true; }
-    // QKV (+ RoPE + cache write): signal groups of head_dim rows — q heads, k heads, v heads
-    SegSpec sq[3];
-    sq[0].W[0] = &Lw.wq; sq[0].x[0] = c->hidden; sq[0].epi = EPI_ROPE_Q; sq[0].out = c->q; sq[0].bias = Lw.bq;
-    sq[1].W[0] = &Lw.wk; sq[1].x[0] = c->hidden; sq[1].epi = EPI_ROPE_K; sq[1].out = Lw.kcache; sq[1].bias = Lw.bk;
-    sq[2].W[0] = &Lw.wv; sq[2].x[0] = c->hidden; sq[2].epi = EPI_V_CACHE; sq[2].out = Lw.vcache; sq[2].bias = Lw.bv;
-    PtHostOp* o = add_mv(sq, 3, Lw.attn_norm, H, in_kind, in_cnt);
-    if (!o) break;
-    const uint32_t qkv_cnt = ncnt;
-    o->op.out_cnt[0] = qkv_cnt; o->op.out_cnt[1] = qkv_cnt + NH; o->op.out_cnt[2] = qkv_cnt + NH + NKV;
-    o->op.out_shift[0] = o->op.out_shift[1] = o->op.out_shift[2] = (uint32_t)ilog2(D);
-    ncnt += NH + 2 * NKV;
-    // attention
-    PtHostOp a{};
-    a.op.kind = PT_ATTN;
-    a.op.next_mv = kPtNone;
-    a.op.attn = 0;   // patched below (index into the PtAttn array)
-    a.attn.q = c->q; a.attn.kc = Lw.kcache; a.attn.vc = Lw.vcache; a.attn.part = c->pt_part; a.attn.pos = c->state + ST_POS;
-    a.attn.scale = scale; a.attn.n_heads = NH; a.attn.n_kv = NKV; a.attn.max_seq = d.max_seq_len;
-    a.attn.in_cnt = qkv_cnt; a.attn.out_cnt = ncnt; a.attn.s_max = c->pt_s_max; a.attn.rows_per_split = c->pt_rows_per_split;
-    const uint32_t attn_cnt = ncnt;
-    ncnt += NKV;
-    ops.push_back(a);
-    const size_t attn_at = ops.size() - 1;
-    // wo (+ residual): its input is merged from the attention partials by the consumer waves
-    qa->fresh = true; qa->tag = nullptr;
-    SegSpec so;
-    so.W[0] = &Lw.wo; so.x[0] = c->attn_out; so.epi = EPI_RESID; so.out = c->hidden; so.resid = c->hidden; so.bias = Lw.bo;
-    so.xq_next = 2; so.xq_next_nw = Lw.ffn_norm;
-    o = add_mv(&so, 1, nullptr, Lw.wo.k, PT_IN_ATTN, attn_cnt);
-    if (!o) break;
-    o->op.attn = (uint32_t)attn_at;   // (ops index for now; translated to the PtAttn index when the image is laid out)
-    o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
-    uint32_t prev_cnt = ncnt;
-    ncnt += H / 256;
-    // gate | up (+ SwiGLU)
-    SegSpec sg;
-    sg.npass = 2; sg.W[0] = &Lw.gate; sg.W[1] = &Lw.up; sg.x[0] = sg.x[1] = c->hidden; sg.epi = EPI_SWIGLU; sg.out = c->act; sg.xq_next = 1;
-    o = add_mv(&sg, 1, Lw.ffn_norm, H, PT_IN_XQ, prev_cnt);
-    if (!o) break;
-    o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
-    prev_cnt = ncnt;
-    ncnt += d.intermediate_size / 256;
-    // down (+ residual)
-    SegSpec sd;
-    sd.W[0] = &Lw.down; sd.x[0] = c->act; sd.epi = EPI_RESID; sd.out = c->hidden; sd.resid = c->hidden;
-    sd.xq_next = next_mfma ? 2 : 0; sd.xq_next_nw = next_nw;
-    o = add_mv(&sd, 1, nullptr, Lw.down.k, PT_IN_XQ, prev_cnt);
-    if (!o) break;
-    if (next_mfma) {
-      o->op.out_cnt[0] = ncnt; o->op.out_shift[0] = 8;
-      in_kind = PT_IN_XQ; in_cnt = ncnt;
-      ncnt += H / 256;
-    }
-  }
-  if (!bad && head) {
-    SegSpec sp;
-    sp.W[0] = &c->output; sp.x[0] = c->hidden; sp.epi = EPI_STORE; sp.out = c->logits;
-    if (!add_mv(&sp, 1, c->output_norm, H, in_kind, in_cnt)) bad = true;
-  }
-  for (auto& q : c->xqs) q.fresh = false;
-  if (bad) { ops.clear(); return no("an op's geometry does not fit the persistent kernel"); }
-  R.mask = ptok_mask(ops.data(), ops.size());
-  if (!R.mask || !ptok_supported(R.mask, D, G)) { ops.clear(); return no("no kernel instantiation for this format mix / head shape"); }
-  R.lds = std::max<size_t>(ptok_layout_lds(ops.data(), ops.size(), D, G), 96 * 1024);   // > half a CU's LDS: one workgroup per CU
-  if (R.lds > 160 * 1024) { ops.clear(); return no("LDS"); }
-  // ---- device image: PtOp[n] | MvLaunch[n_mv] | PtAttn[n_attn]
-  uint32_t n_mv = 0, n_attn = 0;
-  std::vector<uint32_t> attn_index(ops.size(), kPtNone);
-  for (size_t i = 0; i < ops.size(); i++) {
-    if (ops[i].op.kind == PT_MV) ops[i].op.mv = n_mv++;
-    else { attn_index[i] = n_attn; ops[i].op.attn = n_attn++; }
-  }
-  uint32_t last_mv = kPtNone, first_mv = kPtNone;
-  for (size_t i = ops.size(); i-- > 0;) {
-    if (ops[i].op.kind == PT_MV) {
-      ops[i].op.next_mv = last_mv;
-      last_mv = (uint32_t)i;
-      first_mv = (uint32_t)i;
-      if (ops[i].op.in_kind == PT_IN_ATTN) ops[i].op.attn = attn_index[ops[i].op.attn];
-    }
-  }
-  const size_t off_mv = ops.size() * sizeof(PtOp), off_attn = off_mv + (size_t)n_mv * sizeof(MvLaunch);
-  const size_t img_bytes = off_attn + (size_t)n_attn * sizeof(PtAttn);
-  std::vector<uint8_t> img(img_bytes);
-  for (size_t i = 0; i < ops.size(); i++) {
-    std::memcpy(img.data() + i * sizeof(PtOp), &ops[i].op, sizeof(PtOp));
-    if (ops[i].op.kind == PT_MV) std::memcpy(img.data() + off_mv + (size_t)ops[i].op.mv * sizeof(MvLaunch), &ops[i].mv, sizeof(MvLaunch));
-    else std::memcpy(img.data() + off_attn + (size_t)ops[i].op.attn * sizeof(PtAttn), &ops[i].attn, sizeof(PtAttn));
-  }
-  int rc;
-  if ((rc = dev_alloc(c, (void**)&R.dev, img_bytes))) return rc;
-  const size_t sync_words = kPtSyncHeader + (size_t)(ncnt + 1) * kPtCntStride;
-  if ((rc = dev_alloc(c, (void**)&R.sync, sync_words * 4))) return rc;
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(R.dev, img.data(), img_bytes, hipMemcpyHostToDevice));
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemset(R.sync, 0, sync_words * 4));
-  if (const char* e = std::getenv("LGH_PT_DEBUG")) {   // timing experiments (diagnostic builds read the word): bit 0 = never wait
-    const unsigned v = (unsigned)std::atoi(e);
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(R.sync + 48, &v, 4, hipMemcpyHostToDevice));
-  }
-  R.P.ops = reinterpret_cast<const PtOp*>(R.dev);
-  R.P.mv = reinterpret_cast<const MvLaunch*>(R.dev + off_mv);
-  R.P.attn = reinterpret_cast<const PtAttn*>(R.dev + off_attn);
-  R.P.sync = R.sync;
-  R.P.nops = (uint32_t)ops.size();
-  R.P.first_mv = first_mv;
-  R.weight_bytes = bytes;
-  R.usable = true;
-  return LGH_OK;
-}
-
-// One token on the persistent kernel: [embedding | advance + input conversion] -> the token kernel -> [arg-max].
-static int enqueue_token_pt(lgh_ctx* c, int mode) {
-  PtProg& R = c->pt[mode];
-  const lgh_model_desc& d = c->d;
-  int rc;
-  XqBuf* qh = xq_get(c, c->hidden, d.hidden_size);
-  if (!qh) return fail(c, LGH_ALLOCATION_FAILED, "XQ image allocation failed");
-  if (c->first) {
-    if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
-           return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state, qh->xq, R.first_nw, qh->ssq, c->stream);
-         })))
-      return rc;
-  } else {
-    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
-    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)d.hidden_size * 4, [&] {
-           return xq_quantize_launch(c->hidden, R.first_nw, qh->xq, qh->ssq, d.hidden_size, c->stream);
-         })))
-      return rc;
-  }
-  const uint64_t kv_bytes = (uint64_t)(c->l1 - c->l0) * 2 * d.num_kv_heads * (c->pos + 1) * d.head_dim * 4;
-  if ((rc = run_k(c, LGH_K_TOKEN, LGH_SYM_PTOK, R.weight_bytes + kv_bytes, [&] {
-         return ptok_launch(R.P, R.mask, d.head_dim, d.num_heads / d.num_kv_heads, R.lds, c->stream);
-       })))
-    return rc;
-  if (c->last && mode == MODE_GREEDY) {
-    if ((rc = run_k(c, LGH_K_ARGMAX, LGH_SYM_ARGMAX, (uint64_t)d.vocab_size * 4, [&] {
-           return argmax_launch(c->logits, d.vocab_size, c->amax_v, c->amax_i, c->state, c->tok_log, c->stream);
-         })))
-      return rc;
-  }
-  for (auto& q : c->xqs) q.fresh = false;
-  return LGH_OK;
-}
-
 // Everything one token needs, in stream order.  Used eagerly and under graph capture.
 static int enqueue_token(lgh_ctx* c, int mode) {
-  if (c->pt[mode].usable) return enqueue_token_pt(c, mode);
   const lgh_model_desc& d = c->d;
   int rc;
-  const int bump = c->flagging ? 1 : 0;
-  c->flag_origin = c->stream;
-  c->flag_qkv_wait = kFlagNone;
-  c->flag_ev_next = 0;
   for (auto& q : c->xqs) q.fresh = false;   // the residual stream is (re)written in f32 now (embedding / previous stage)
   if (c->first) {
     // the embedding row, and — when the first layer's QKV runs on the matrix cores — its XQ image with that layer's norm weights
@@ -1006,12 +606,12 @@ static int enqueue_token(lgh_ctx* c, int mode) {
     }
     if ((rc = run_k(c, LGH_K_EMBED, LGH_SYM_EMBED, (uint64_t)d.hidden_size * blk_bytes(c->embd_type) / blk_elems(c->embd_type), [&] {
            return embed_launch(c->embd_type, c->embd_raw, c->state + ST_TOKEN, c->hidden, d.hidden_size, c->state,
-                               qh ? qh->xq : nullptr, nw0, qh ? qh->ssq : nullptr, c->stream, bump);
+                               qh ? qh->xq : nullptr, nw0, qh ? qh->ssq : nullptr, c->stream);
          })))
       return rc;
     if (qh) { qh->fresh = true; qh->tag = nw0; }
   } else {
-    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream, bump); }))) return rc;
+    if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return advance_launch(c->state, c->stream); }))) return rc;
   }
   for (uint32_t li = c->l0; li < c->l1; li++) {
     // who consumes this layer's output: the next layer's QKV (attn_norm), the output projection (output_norm), or — at a
@@ -1025,11 +625,7 @@ static int enqueue_token(lgh_ctx* c, int mode) {
       next_nw = c->output_norm;
       next_mfma = mfma_type(c->output.type);
     }
-    if ((rc = layer_forward(c, li, next_nw, next_mfma, mode))) { c->stream = c->flag_origin; return rc; }
-  }
-  if (c->flag_ev_next) {   // flag-ordered launches were enqueued: whatever the other stream still carries joins the origin here
-    c->stream = c->flag_origin;
-    if ((rc = flag_edge(c, c->stream2, c->flag_origin))) return rc;
+    if ((rc = layer_forward(c, li, next_nw, next_mfma, mode))) return rc;
   }
   if (c->last && mode != MODE_PREFILL) {
     // compute_logits (llama.rs:247-266): final RMSNorm fused into the output projection
@@ -1044,8 +640,6 @@ static int enqueue_token(lgh_ctx* c, int mode) {
   return LGH_OK;
 }
 
-static int check_chain(lgh_ctx* c);
-
 // One token through the context's kernels, launched eagerly, before any of them is first launched inside a stream
 // capture.  Measured on ROCm 7.0 / MI355X: a kernel whose FIRST launch in the process happens during a capture is not
 // replayed with the graph — a pipeline stage behind the first (advance + stand-alone XQ kernels, which only such stages
@@ -1055,56 +649,29 @@ static int check_chain(lgh_ctx* c);
 static int warm_kernels(lgh_ctx* c) {
   if (c->d.flags & LGH_FLAG_NO_GRAPH) return LGH_OK;
   int rc = LGH_OK;
-  const bool keep_direct = c->attn_direct, keep_merge = c->attn_merge;
-  for (int v = 0; v < 3 && !rc; v++) {
-    if ((v == 1 && c->direct_attn_max_kv == 0) || (v == 2 && c->merge_attn_max_kv == 0)) continue;
+  const bool keep_direct = c->attn_direct;
+  for (int v = 0; v < 2 && !rc; v++) {
+    if (v == 1 && c->direct_attn_max_kv == 0) continue;
     c->attn_direct = v == 1;
-    c->attn_merge = v == 2;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
     for (int mode : {c->last ? MODE_GREEDY : MODE_PREFILL, MODE_PREFILL})   // the last stage: with and without the output head
       if (!rc) rc = enqueue_token(c, mode);
   }
-  if (!rc && c->flag_mode) {
-    // the flag-ordered instantiations must also have been launched once outside a capture (the trap described above); eagerly
-    // the two streams and their events work exactly as they do in the captured graph
-    c->attn_direct = c->attn_merge = false;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-    c->flagging = true;
-    rc = enqueue_token(c, c->last ? MODE_GREEDY : MODE_PREFILL);
-    c->flagging = false;
-    (void)hipStreamSynchronize(c->stream2);
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-    // the warm-up token went through the counters like any other: the epoch word must survive the state reset below
-  }
   c->attn_direct = keep_direct;
-  c->attn_merge = keep_merge;
   for (auto& q : c->xqs) q.fresh = false;
   if (rc) return rc;
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_EPOCH * 4, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->state, 0, ST_WORDS * 4, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return check_chain(c);
+  return LGH_OK;
 }
 
 static int ensure_graph(lgh_ctx* c, int mode) {
-  const int var = c->attn_direct ? 1 : c->attn_merge ? 2 : 0;
+  const int var = c->attn_direct ? 1 : 0;
   if (c->graph[mode][var]) return LGH_OK;
   hipGraph_t g = nullptr;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-  c->chain_pending.clear();
-  c->flagging = c->flag_mode;
   int rc = enqueue_token(c, mode);
-  c->flagging = false;
   hipError_t e = hipStreamEndCapture(c->stream, &g);
-  for (ChainSlot* slot : c->chain_pending) {   // descriptor images of the chained launches (static per mode and layer)
-    if (rc || e != hipSuccess || slot->uploaded) continue;
-    if (hipMemcpy(slot->dev, slot->host.op, sizeof(MvLaunch) * kChainMaxOps, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(slot->dev + sizeof(MvLaunch) * kChainMaxOps, slot->host.geo, sizeof(MvChainOp) * kChainMaxOps, hipMemcpyHostToDevice) != hipSuccess)
-      rc = fail(c, LGH_OPERATION_FAILED, "chain descriptor upload failed");
-    else
-      slot->uploaded = true;
-  }
-  c->chain_pending.clear();
   if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess) return fail(c, LGH_OPERATION_FAILED, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
   size_t n_nodes = 0;
@@ -1121,48 +688,17 @@ static int step(lgh_ctx* c, int mode) {
   if (c->pos >= c->d.max_seq_len)  // the reference has no such check: OOB write past the KV capacity
     return fail(c, LGH_INVALID_ARGUMENT, "position " + std::to_string(c->pos) + " >= max_seq_len " + std::to_string(c->d.max_seq_len));
   int rc;
-  // the token at position pos attends to pos + 1 rows (the persistent token kernel picks its splits on the device)
-  c->attn_direct = !c->pt[mode].usable && c->pos + 1 <= c->direct_attn_max_kv;
-  c->attn_merge = !c->pt[mode].usable && !c->attn_direct && c->pos + 1 <= c->merge_attn_max_kv;
+  c->attn_direct = c->pos + 1 <= c->direct_attn_max_kv;   // the token at position pos attends to pos + 1 rows
   if (c->profiling || (c->d.flags & LGH_FLAG_NO_GRAPH)) {
     if ((rc = enqueue_token(c, mode))) return rc;
     if (c->profiling && (rc = drain_prof(c))) return rc;
   } else {
     if ((rc = ensure_graph(c, mode))) return rc;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode][c->attn_direct ? 1 : c->attn_merge ? 2 : 0], c->stream));
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipGraphLaunch(c->graph[mode][c->attn_direct ? 1 : 0], c->stream));
   }
   c->pos += 1;
   c->stats.tokens_processed += 1;
   return LGH_OK;
-}
-
-// a chained launch whose grid barrier timed out raised this flag (bounded spins: the launch still ran to completion)
-static int check_chain(lgh_ctx* c) {
-  for (int m = 0; m < MODE_COUNT; m++) {   // a hand-off wait of the persistent token kernel that ran into its spin limit
-    if (!c->pt[m].usable) continue;
-    unsigned flag = 0;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->pt[m].sync + 16, 4, hipMemcpyDeviceToHost));
-    if (flag) return fail(c, LGH_OPERATION_FAILED, "a hand-off wait of the persistent token kernel timed out (code " + std::to_string(flag) + ")");
-  }
-  if (c->flag_sync) {   // a flag-ordered launch whose wait ran into its spin limit
-    unsigned f2 = 0;
-    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&f2, c->flag_sync + 16, 4, hipMemcpyDeviceToHost));
-    if (f2) {
-      unsigned w[4] = {0, 0, 0, 0};
-      int ep = 0;
-      (void)hipMemcpy(w, c->flag_sync + 16, 16, hipMemcpyDeviceToHost);
-      (void)hipMemcpy(&ep, c->state + ST_EPOCH, 4, hipMemcpyDeviceToHost);
-      std::string where = "?";
-      for (size_t i = 0; i < c->flag_cnt.size(); i++)   // which launch's records the waiter was after
-        if (c->flag_cnt[i] != kFlagNone && c->flag_cnt[i] <= w[1]) where = "layer " + std::to_string(c->l0 + i / 3) + (i % 3 == 0 ? " wo" : i % 3 == 1 ? " gate/up" : " down");
-      return fail(c, LGH_OPERATION_FAILED, "a hand-off wait of a flag-ordered launch timed out (records of " + where + ", counter " + std::to_string(w[1]) +
-                  ": target " + std::to_string(w[2]) + ", seen " + std::to_string(w[3]) + ", token epoch " + std::to_string(ep) + ")");
-    }
-  }
-  if (!c->chain_sync) return LGH_OK;
-  unsigned flag = 0;
-  HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(&flag, c->chain_sync + 576, 4, hipMemcpyDeviceToHost));
-  return flag ? fail(c, LGH_OPERATION_FAILED, "grid barrier of a chained launch timed out (code " + std::to_string(flag) + ")") : LGH_OK;
 }
 
 static int bind(const lgh_ctx* c) { return hipSetDevice(c->device) == hipSuccess ? LGH_OK : LGH_NOT_AVAILABLE; }
@@ -1355,7 +891,7 @@ int engine_shape_check(const lgh_model_desc& d, std::string& why) {
           "kernel, which holds max_seq_len scores in LDS: max_seq_len must be <= 38400 for it (got " + std::to_string(d.max_seq_len) + ")";
     return LGH_UNSUPPORTED;
   }
-  if ((d.flags & LGH_FLAG_KV_INT8) && (!attn_shape_has_fast_kernel(d.head_dim, g) || (d.flags & (LGH_FLAG_PERSISTENT | LGH_FLAG_CHAIN_FFN)))) {
+  if ((d.flags & LGH_FLAG_KV_INT8) && !attn_shape_has_fast_kernel(d.head_dim, g)) {
     why = "the int8 KV cache runs on the split attention kernels (head_dim 64 / 128; 1, 2, 4 or 8 query heads per kv head) of the default decode path";
     return LGH_UNSUPPORTED;
   }
@@ -1384,6 +920,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   std::memcpy(&d, desc, desc->struct_size);
   d.struct_size = sizeof(lgh_model_desc);
   if (d.kv_cache_type > LGH_KV_FP8_E5M2) return LGH_INVALID_ARGUMENT;
+  if (d.flags & LGH_FLAG_REMOVED_MASK) return LGH_UNSUPPORTED;   // the decode structures removed in round 3 (llama_gguf_hip.h)
   if (d.kv_cache_type == LGH_KV_F32 && (d.flags & LGH_FLAG_KV_INT8)) d.kv_cache_type = LGH_KV_INT8;
   // every byte-per-element cache shares the int8 cache's structure (staged f32 rows, the attention launch quantizes and stores
   // the current token's rows): the flag marks all of them from here on, kv_cache_type tells them apart
@@ -1415,17 +952,9 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   }
   if (splits > 32) splits = 32;   // the split merge keeps one partial per split in registers
   c->n_splits = splits;
-  c->attn_fuse = (d.flags & LGH_FLAG_ATTN_FUSED) != 0;
   const uint32_t dsel = (d.flags >> LGH_FLAG_ATTN_DIRECT_SHIFT) & 0xFFu;
   c->direct_attn_max_kv = dsel == 255 ? 0 : dsel ? dsel * 64 : kDirectAttnDefaultKv;
-  // split + merge-in-wo: contexts up to 64 * n rows (bits 24..31; 0 = the tuned default, 255 = never).  Needs the output
-  // projection on the matrix cores (checked per layer) and 64 | head_dim.
-  const uint32_t msel = (d.flags >> LGH_FLAG_ATTN_MERGE_SHIFT) & 0xFFu;
-  c->merge_attn_max_kv = msel == 255 ? 0 : msel ? msel * 64 : kMergeAttnDefaultKv;
-  if (c->merge_attn_max_kv && c->merge_attn_max_kv <= c->direct_attn_max_kv) c->merge_attn_max_kv = 0;
-  if (d.flags & LGH_FLAG_KV_INT8) c->direct_attn_max_kv = c->merge_attn_max_kv = 0;   // the int8 cache has one attention structure: splits + combine
-  if ((d.num_heads * d.head_dim) % 256 || d.head_dim % 64 || (d.flags & LGH_FLAG_CHAIN_FFN)) c->merge_attn_max_kv = 0;
-  if (const char* e = std::getenv("LGH_MERGE_SPLITS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) c->merge_splits = (uint32_t)v; }
+  if (d.flags & LGH_FLAG_KV_INT8) c->direct_attn_max_kv = 0;   // the byte caches have one attention structure: splits + combine
   *out = c;
   return LGH_OK;
 }
@@ -1605,7 +1134,6 @@ int lgh_finalize(lgh_ctx* c) {
       {(void**)&c->act, ffn * 4},
       {(void**)&c->act2, ffn * 4},
       {(void**)&c->logits, (size_t)d.vocab_size * 4},
-      {(void**)&c->attn_arrive, (size_t)d.num_kv_heads * 16 * 4},
       {(void**)&c->part_ml, (size_t)d.num_kv_heads * c->n_splits * G * 2 * 4},
       {(void**)&c->part_acc, (size_t)d.num_kv_heads * c->n_splits * G * d.head_dim * 4},
       {(void**)&c->rope_cs, (size_t)d.max_seq_len * d.head_dim * 4},
@@ -1620,18 +1148,6 @@ int lgh_finalize(lgh_ctx* c) {
     if ((rc = dev_alloc(c, b.p, b.n))) return rc;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
-  }
-  if (d.flags & LGH_FLAG_CHAIN_FFN) {
-    // the chained launch is kNumCU workgroups that wait for each other: every one of them must be resident, i.e. the
-    // device must really have that many CUs to give (otherwise the flag is ignored)
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus >= kNumCU) {
-      c->chains.assign((size_t)MODE_COUNT * d.num_layers, ChainSlot{});
-      for (auto& slot : c->chains)   // device images allocated here, never during a graph capture
-        if ((rc = dev_alloc(c, (void**)&slot.dev, sizeof(MvLaunch) * kChainMaxOps + sizeof(MvChainOp) * kChainMaxOps))) return rc;
-      if ((rc = dev_alloc(c, (void**)&c->chain_sync, kChainSyncWords * 4))) return rc;
-      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(c->chain_sync, 0, kChainSyncWords * 4, c->stream));
-    }
   }
   // XQ images of the vectors that feed quantized mat-vecs (allocated here, never during a graph capture)
   if (!xq_get(c, c->hidden, d.hidden_size) || !xq_get(c, c->attn_out, d.num_heads * d.head_dim) || !xq_get(c, c->act, (uint32_t)ffn) ||
@@ -1655,87 +1171,6 @@ int lgh_finalize(lgh_ctx* c) {
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   c->finalized = true;
   c->pos = 0;
-  if ((d.flags & (LGH_FLAG_OVERLAP | LGH_FLAG_FLOW_FFN)) && !(d.flags & (LGH_FLAG_NO_GRAPH | LGH_FLAG_CHAIN_FFN | LGH_FLAG_PERSISTENT)) && d.hidden_size % 256 == 0 &&
-      (d.num_heads * d.head_dim) % 256 == 0) {
-    // flag-ordered graphs (handoff.h): across which edges of wo -> gate-up -> down -> next QKV the consumer may be dispatched
-    // beside its producer.  A consumer spins on counters while it waits: it must never hold a CU that a workgroup of its
-    // producer still needs, so BOTH launches must fit on a CU together — registers (two waves per SIMD each, 512 per SIMD
-    // lane) and LDS — and then every CU has room for one workgroup of each (no launch has more workgroups than CUs).
-    // MEASURED (tools/ov_debug.py, Llama-3-8B): a Q6_K down projection at 144 registers beside a 120-register gate-up
-    // deadlocked now and then (its workgroups took the CUs that gate-up's last workgroups were still to be placed on).
-    auto fmt_mask = [](int dev_type) -> uint32_t {
-      return dev_type == kDevQ4K_T16 ? 1u : dev_type == kDevQ6K_T16 ? 2u : dev_type == kDevQ5K_T16 ? 4u : dev_type == kDevQ80_T16 ? 8u : dev_type == kDevQ40_T16 ? 16u : 0u;
-    };
-    struct Fit { int regs; size_t lds; };
-    auto fit_of = [&](uint32_t mask, uint32_t k, int npass) -> Fit {
-      const int r = mask ? mvq_kernel_regs(mask, true) : -1;
-      // LDS: the XQ records of the input (8 waves' k-slices together: the whole vector) + partial sums + slack
-      return {r <= 0 ? -1 : (r + 7) / 8 * 8, (size_t)k / 256 * kXqRecord + (size_t)npass * 8192 + 1024};
-    };
-    auto fits = [](const Fit& a, const Fit& b) { return a.regs > 0 && b.regs > 0 && a.regs + b.regs <= 256 && a.lds + b.lds <= 160 * 1024; };
-    auto qkv_fit = [&](const LayerW& L) -> Fit {
-      if (!(fused_type(L.wq.type) && fused_type(L.wk.type) && fused_type(L.wv.type)) || d.use_neox_rope) return {-1, 0};
-      if (!(mfma_type(L.wq.type) && mfma_type(L.wk.type) && mfma_type(L.wv.type))) return {-1, 0};
-      return fit_of(fmt_mask(L.wq.type) | fmt_mask(L.wk.type) | fmt_mask(L.wv.type), d.hidden_size, 1);
-    };
-    const bool flow_wanted = (d.flags & LGH_FLAG_FLOW_FFN) != 0;
-    c->flag_cnt.assign((size_t)(c->l1 - c->l0) * 3, kFlagNone);
-    c->flag_edges.assign((size_t)(c->l1 - c->l0), 0u);
-    uint32_t ncnt = 0;
-    for (uint32_t i = c->l0; i < c->l1; i++) {
-      const LayerW& L = c->layers[i];
-      if (L.moe() || d.intermediate_size % 256 || L.gate.type != L.up.type) {
-        if (std::getenv("LGH_DEBUG_OVERLAP")) std::fprintf(stderr, "[lgh] layer %u: moe %d, gate type %d, up type %d\n", i, (int)L.moe(), L.gate.type, L.up.type);
-        continue;
-      }
-      bool ok = true;
-      for (const DevWeight* W : {&L.wo, &L.gate, &L.up, &L.down}) ok = ok && mfma_type(W->type) && W->n % 16 == 0;
-      if (std::getenv("LGH_DEBUG_OVERLAP") && !ok)
-        std::fprintf(stderr, "[lgh] layer %u: types wo %d gate %d up %d down %d not all on the matrix cores\n", i, L.wo.type, L.gate.type, L.up.type, L.down.type);
-      if (!ok) continue;
-      const Fit fw = fit_of(fmt_mask(L.wo.type), L.wo.k, 1), fg = fit_of(fmt_mask(L.gate.type), d.hidden_size, 2),
-                fd = fit_of(fmt_mask(L.down.type), d.intermediate_size, 1);
-      uint32_t e = 0;
-      if (fits(fw, fg)) e |= 1u;
-      if (fits(fg, fd)) e |= 2u;
-      if (i + 1 < c->l1 && fits(fd, qkv_fit(c->layers[i + 1]))) e |= 4u;
-      // flow launch (one launch for the three ops): every op's body under half the registers, twice the largest LDS need fits
-      if (flow_wanted && fw.regs <= 128 && fg.regs <= 128 && fd.regs <= 128 && 2 * std::max(fw.lds, std::max(fg.lds, fd.lds)) <= 160 * 1024) e |= 8u;
-      if (std::getenv("LGH_DEBUG_OVERLAP"))
-        std::fprintf(stderr, "[lgh] layer %u: wo %d regs %zu B, gate/up %d regs %zu B, down %d regs %zu B -> edges %u\n", i, fw.regs, fw.lds, fg.regs,
-                     fg.lds, fd.regs, fd.lds, e);
-      if (!e) continue;
-      c->flag_edges[i - c->l0] = e;
-      uint32_t* cnt = &c->flag_cnt[(size_t)(i - c->l0) * 3];
-      cnt[0] = ncnt; ncnt += d.hidden_size / 256;
-      cnt[1] = ncnt; ncnt += d.intermediate_size / 256;
-      cnt[2] = ncnt; ncnt += d.hidden_size / 256;
-    }
-    if (ncnt) {
-      const size_t words = kHoHeader + (size_t)(ncnt + 1) * kHoCntStride;
-      if ((rc = dev_alloc(c, (void**)&c->flag_sync, words * 4))) return rc;
-      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemset(c->flag_sync, 0, words * 4));
-      HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-      c->flag_events.assign((size_t)(c->l1 - c->l0) * 2 + 8, nullptr);
-      for (auto& e : c->flag_events) HIP_TRY(c, LGH_OPERATION_FAILED, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      c->flag_mode = true;
-      if (flow_wanted) {
-        c->flows.assign((size_t)MODE_COUNT * d.num_layers, ChainSlot{});
-        for (auto& slot : c->flows)   // device images allocated here, never during a graph capture
-          if ((rc = dev_alloc(c, (void**)&slot.dev, sizeof(MvLaunch) * kChainMaxOps + sizeof(MvChainOp) * kChainMaxOps))) return rc;
-        c->flow_mode = true;
-      }
-    }
-  }
-  {  // the persistent token kernel's programs, one per graph mode (allocated here, never during a graph capture)
-    const uint32_t G = d.num_heads / d.num_kv_heads;
-    uint32_t smax = kNumCU / d.num_kv_heads;
-    c->pt_s_max = smax < 1 ? 1 : (smax > 32 ? 32 : smax);
-    if (const char* e = std::getenv("LGH_PT_ROWS_PER_SPLIT")) { const int v = std::atoi(e); if (v >= 8 && v <= 4096) c->pt_rows_per_split = (uint32_t)v; }
-    if ((rc = dev_alloc(c, (void**)&c->pt_part, pt_part_floats(d.num_kv_heads, c->pt_s_max, G, d.head_dim) * 4))) return rc;
-    for (int m = 0; m < MODE_COUNT; m++)
-      if ((rc = pt_build(c, m))) return rc;
-  }
   return warm_kernels(c);
 }
 
@@ -1744,13 +1179,10 @@ void lgh_destroy(lgh_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (int m = 0; m < MODE_COUNT; m++)
-    for (int v = 0; v < 3; v++)
+    for (int v = 0; v < 2; v++)
       if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
-  for (hipEvent_t e : c->flag_events)
-    if (e) (void)hipEventDestroy(e);
-  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
   if (c->pf.tok_pinned) (void)hipHostFree(c->pf.tok_pinned);
   if (c->pf.tok_copied) (void)hipEventDestroy(c->pf.tok_copied);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1773,7 +1205,7 @@ int lgh_forward(lgh_ctx* c, uint32_t token, float* logits_out) {
   if ((rc = step(c, MODE_FORWARD))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return check_chain(c);
+  return LGH_OK;
 }
 
 int lgh_prefill_token(lgh_ctx* c, uint32_t token) {
@@ -1910,7 +1342,7 @@ int lgh_decode_greedy(lgh_ctx* c, uint32_t first_token, size_t n_steps, uint32_t
     if ((rc = step(c, MODE_GREEDY))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(tokens_out, c->tok_log + pos0, n_steps * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return check_chain(c);
+  return LGH_OK;
 }
 
 const char* lgh_last_error(const lgh_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -1938,8 +1370,6 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
   }
   c->stats.step_alg_bytes = b;
   c->stats.overlapped_edges = 0;
-  if (c->flag_mode)
-    for (uint32_t e : c->flag_edges) c->stats.overlapped_edges += (uint64_t)__builtin_popcount(e);
   *out = c->stats;
   return LGH_OK;
 }
@@ -1967,7 +1397,7 @@ int lgh_set_stream(lgh_ctx* c, void* s) {
   hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
   if (ns != c->stream) {
     for (int m = 0; m < MODE_COUNT; m++)
-      for (int v = 0; v < 3; v++)
+      for (int v = 0; v < 2; v++)
         if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
   }
   c->stream = ns;
@@ -2041,7 +1471,7 @@ int lgh_stage_read_logits(lgh_ctx* c, float* logits_out) {
   if (!c->last) return fail(c, LGH_INVALID_ARGUMENT, "only the last stage holds logits");
   HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(logits_out, c->logits, (size_t)c->d.vocab_size * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
-  return check_chain(c);
+  return LGH_OK;
 }
 
 int lgh_stage_read_tokens(lgh_ctx* c, size_t pos0, size_t n, uint32_t* out) {

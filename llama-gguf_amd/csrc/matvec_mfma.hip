@@ -28,7 +28,6 @@
 #include "mv_epilogue.h"
 #include "xq.h"
 #include "mvq_core.h"
-#include "handoff.h"
 #include "timeline.h"
 
 LGH_TL_DEFINE(mvq)
@@ -312,56 +311,6 @@ hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, floa
   return hipGetLastError();
 }
 
-// The decode attention's split partials -> this wave's k-slice of the attention output, as XQ records in its LDS region
-// (MvLaunch::attn_*).  Elements [blk0 * 256, (blk0 + nblk_w) * 256); 64 consecutive elements belong to one head (64 divides
-// head_dim).  Per 512 elements ONE memory round trip: the (m, l) of every (step, split) and all accumulators are requested
-// before any is used (up to 8 splits; attention.hip's layout part_ml [(kv head, split, g)][2], part_acc [(kv head, split, g)][D]);
-// out = sum_s acc_s e^(m_s - m*) / sum_s l_s e^(m_s - m*), as attn_combine_kernel computes it.
-constexpr uint32_t kMergeMaxSplits = 8;
-__device__ __forceinline__ void mvq_gather_attn(const float* __restrict__ pml, const float* __restrict__ pacc, uint32_t S, uint32_t G,
-                                                uint32_t dshift, uint32_t blk0, uint32_t nblk_w, uint8_t* xrec, uint32_t lane) {
-  const uint32_t D = 1u << dshift, e0 = blk0 * 256;
-  for (uint32_t it0 = 0; it0 < nblk_w * 4; it0 += 8) {
-    const uint32_t nst = min(8u, nblk_w * 4 - it0);    // steps of 64 elements in this group (4 or 8)
-    float ms[8], ls[8], v[8][kMergeMaxSplits];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t jj = (uint32_t)j < nst ? (uint32_t)j : 0u;
-      const uint32_t e = e0 + (it0 + jj) * 64 + lane, h = e >> dshift, dim = e & (D - 1), kvh = h / G, g = h - kvh * G;
-      const uint32_t sl = lane & 7;
-      const size_t im = ((size_t)kvh * S + (sl < S ? sl : 0)) * G + g;
-      ms[j] = pml[im * 2];
-      ls[j] = pml[im * 2 + 1];
-#pragma unroll
-      for (uint32_t t = 0; t < kMergeMaxSplits; t++)
-        v[j][t] = pacc[((((size_t)kvh * S + (t < S ? t : 0)) * G + g) << dshift) + dim];
-    }
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if ((uint32_t)j < nst) {
-        // lanes 8i .. 8i+7 hold splits 0..7 of this step's head: max / sum within the group of 8 by DPP
-        const bool live = (lane & 7) < S;
-        float m = live ? ms[j] : -1e30f;
-        float mn = fmaxf(m, dpp_f<0xB1>(m));
-        mn = fmaxf(mn, dpp_f<0x4E>(mn));
-        mn = fmaxf(mn, dpp_f<0x141>(mn));                 // row_half_mirror: lanes i <-> 7 - i within each 8
-        const float f = live ? expf(m - mn) : 0.0f;
-        float lsum = ls[j] * f;
-        lsum += dpp_f<0xB1>(lsum);
-        lsum += dpp_f<0x4E>(lsum);
-        lsum += dpp_f<0x141>(lsum);
-        float a = 0.0f;
-#pragma unroll
-        for (uint32_t t = 0; t < kMergeMaxSplits; t++) {
-          const float ft = __shfl(f, (int)((lane & ~7u) + t), 64);   // split t's weight, from this lane's own group of 8
-          a = __builtin_fmaf(v[j][t], t < S ? ft : 0.0f, a);
-        }
-        xq_store_chunk<false>(xrec, (it0 + j) * 4 + (lane >> 4), a * (1.0f / lsum), nullptr, 0.0f, lane);   // simd.rs:718-720: x 1/sum
-      }
-    }
-  }
-}
-
 constexpr int kWaves = 8;   // waves per workgroup: 2 per SIMD, 256 VGPRs each
 constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x 8 waves = 72 KiB per CU)
 
@@ -380,10 +329,7 @@ constexpr int kDepth = 4;   // weight tiles a wave keeps in flight (4 x 2304 B x
 // geom  = T | G << 8 | nbw << 16 | do_norm << 31         geom2 = nblk | Rg << 16        wbpack = wg_begin[1] | wg_begin[2] << 16
 // offA/B/C = byte strides of a workgroup / a row-group / a k-slice inside one pass's tile array
 // MASK: the formats (1 << F_*) the instantiation handles; with more than one the segment's type decides at run time
-// COH: the op runs inside a chain (mvq_chain_kernel): its inputs may have been written earlier in the same launch by
-// workgroups on other XCDs, and its outputs are read later in the same launch — agent-scope loads / write-through stores.
-// FLAG: a flag-ordered launch (MvLaunch::flag_*, handoff.h; implies COH): tiles first, then the wait for the input's records.
-template <uint32_t MASK, bool COH, bool ATTN = false, bool FLAG = false, bool FLOW = false>
+template <uint32_t MASK>
 __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                          uint32_t lds_red_off, const MvLaunch& L, uint8_t* smem8) {
   // the position word (RoPE epilogues): its scalar load goes out with the very first kernarg loads, no wait here
@@ -398,17 +344,13 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   const float* S_xq_nw = S.xq_nw;
   const float* L_rope_cs = L.rope_cs;
   constexpr bool kSingle = (MASK & (MASK - 1)) == 0;
-  // weight tiles in flight per wave.  A flag-ordered launch shares its CU with its producer (two workgroups, half the
-  // registers each): the two formats with 5-load tiles keep a ring of three there, which brings every single-format
-  // flag-ordered instantiation under 128 registers — ANY two of them then fit side by side (test_build_props.py)
-    constexpr int kDp = FLAG && (MASK == (1u << F_Q6K) || MASK == (1u << F_Q80)) ? kDepth - 1 : kDepth;
+  constexpr int kDp = kDepth;   // weight tiles in flight per wave
   const int fmt = kSingle ? __builtin_ctz(MASK) : fmt_of_dev_type(S.type);
   auto is = [&](int f) { return ((MASK >> f) & 1u) != 0 && (kSingle || fmt == f); };   // compile-time false for absent formats
   const uint32_t tb = is(F_Q4K) ? fmt_tile_bytes(F_Q4K) : is(F_Q6K) ? fmt_tile_bytes(F_Q6K) : is(F_Q5K) ? fmt_tile_bytes(F_Q5K)
                       : is(F_Q80) ? fmt_tile_bytes(F_Q80) : fmt_tile_bytes(F_Q40);
   const uint32_t S_T = geom & 0xFFu, S_G = (geom >> 8) & 0xFFu, nbw = (geom >> 16) & 0x3FFFu;
   const bool nrm = (geom >> 31) != 0;
-  constexpr bool from_attn = ATTN;   // the input vector is merged from the attention's split partials (geom bit 30, host-checked)
   const uint32_t S_nblk = geom2 & 0xFFFFu;
   // tiles per workgroup and row group: launch-uniform for a single matrix, per segment in a fused launch (S_G is a power of two)
   const uint32_t Rg = L.nseg > 1 ? S.rows_per_wg >> (4 + __builtin_ctz(S_G)) : geom2 >> 16;
@@ -474,28 +416,11 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   auto load_ssp = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (lane + 64 * j < L_n_ssq) ssp[j] = coh_load<COH>(L_ssq_part + lane + 64 * j);
+      if (lane + 64 * j < L_n_ssq) ssp[j] = L_ssq_part[lane + 64 * j];
   };
-  if (!FLAG && nrm && wave == 0) load_ssp();
-  // flag-ordered launch: the producer of the input vector may still be running.  A wave waits for the records of its own
-  // k-slice; wave 0, which adds up ALL the producer's sums of squares when there is a norm, for every record.
+  if (nrm && wave == 0) load_ssp();
   MvEpiPre epi_pre = {0.0f, 0.0f, false};
-  bool flag_synced = !FLAG;
-  auto flag_sync = [&]() {
-    if (flag_synced) return;
-    flag_synced = true;
-    if (L.flag_sync && L.flag_wait_first != kFlagNone) {
-      unsigned ep;
-      asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ep) : "s"(L.flag_epoch) : "memory");
-      const bool all = nrm && wave == 0;
-      const uint32_t first = all ? 0u : blk0, cnt = all ? S_nblk : nblk_w;
-      for (uint32_t b = 0; b < cnt; b += 64) ho_wait(L.flag_sync, L.flag_wait_first + first + b, min(64u, cnt - b), ep * 256u, lane);
-    }
-    if (nrm && wave == 0) load_ssp();
-  };
-  // FLOW (several ops in one launch): the residual of an op that waits is a vector an EARLIER op of the same launch rewrites
-  // (wo's output is down's residual) — not valid yet; the epilogue loads it itself then
-  if (!(FLOW && L.flag_wait_first != kFlagNone)) mv_epilogue_prefetch_resid<COH>(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
+  mv_epilogue_prefetch_resid(S_epi, S_resid, S_xq_nw, S_nrows, wg, S_rpw, epi_pre);
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pos_now));   // long since there: the kernarg batch above was waited for
   mv_epilogue_prefetch_rope(S_epi, pos_now, L_rope_cs, S_head_dim, S_nrows, wg, S_rpw, epi_pre);
   LGH_WSTAMP(1);
@@ -547,14 +472,9 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
         const uint8_t* src = xg + b * kXqRecord;
         const uint32_t dst = xrec_lds + b * kXqRecord;
         uint32_t keep;
-        if (COH)   // records written earlier in this launch by another XCD: agent-scope (sc1) loads
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off sc1\n\ts_add_u32 m0, m0, 0x400\n\t"
-                       "s_nop 0\n\tglobal_load_lds_dword %2, off sc1\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
-        else
-          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\t"
-                       "s_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
-                       : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\t"
+                     "s_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 4), "s"(dst) : "memory");
       }
     };
     auto x_finish = [&](auto n_tiles) {
@@ -587,26 +507,10 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
     auto run = [&](auto n_first) {
       constexpr int NF = decltype(n_first)::value;
       LGH_WSTAMP(2);
-      if constexpr (from_attn) {
-        // tiles first (they do not depend on anything), then the partials: the merged k-slice is complete when the first
-        // tiles have landed (loads return in order)
+      x_request();
 #pragma unroll
-        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
-        mvq_gather_attn(L.attn_ml, L.attn_acc, L.attn_splits, L.attn_g, L.attn_dshift, blk0, nblk_w, const_cast<uint8_t*>(xrec), lane);
-      } else if constexpr (FLAG) {
-        // the weight tiles do not depend on anything: in flight before the producer of x is even done; then its counters,
-        // then the records (agent-scope loads); everything issued so far has landed when the records have
-#pragma unroll
-        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
-        flag_sync();
-        x_request();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        x_request();
-#pragma unroll
-        for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
-        x_finish(n_first);
-      }
+      for (int j = 0; j < NF; j++) { pos[j] = nx; issue(nx, buf[j]); advance(); }
+      x_finish(n_first);
       LGH_WSTAMP(5);
       if constexpr (NF < kDp) {   // that was everything
 #pragma unroll
@@ -652,10 +556,9 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
     LGH_STAMP(3);
     LGH_WSTAMP(6);
   }
-  if constexpr (FLAG) flag_sync();   // (a wave without tiles has not waited yet)
   if (nrm && wave == 0) {   // the producer's partial sums of x^2 -> ssq[0]; the other waves contribute nothing
     float ss = (ssp[0] + ssp[1]) + (ssp[2] + ssp[3]);
-    for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += coh_load<COH>(L_ssq_part + i);
+    for (uint32_t i = 256 + lane; i < L_n_ssq; i += 64) ss += L_ssq_part[i];
     ss = wave_sum_to_lane63(ss);
     if (lane == 63) ssq[0] = ss;
   } else if (nrm && lane == 0) {
@@ -663,131 +566,19 @@ __device__ __forceinline__ void mvq_body(const uint32_t bid, uint32_t wbpack, ui
   }
   __syncthreads();
   LGH_STAMP(4);
-  mv_epilogue<COH>(L, S, wg, red, ssq, S_T, epi_pre);
-  if constexpr (FLAG) {
-    if (L.flag_sync && L.flag_sig_first != kFlagNone && s == 0) {   // publish: stores drained by every wave, then one wave signals
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (wave == 0) ho_signal_rows(L.flag_sync, L.flag_sig_first, 8, wg * S_rpw, min(wg * S_rpw + S_rpw, S_nrows), lane);
-    }
-  }
+  mv_epilogue(L, S, wg, red, ssq, S_T, epi_pre);
   LGH_STAMP(5);
   LGH_WSTAMP(7);
   LGH_SPAN(1);
 }
 
-template <uint32_t MASK, bool ATTN = false>
+template <uint32_t MASK>
 __global__ void __launch_bounds__(kWaves * 64) mvq_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
                                                           uint32_t lds_red_off, const MvLaunch L) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   LGH_TL_BEGIN(mvq, lgh::TL_MVQ, geom2);
-  mvq_body<MASK, false, ATTN, false>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
+  mvq_body<MASK>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
   LGH_TL_END();
-}
-
-// Flag-ordered launches (handoff.h) run BESIDE their producer, two workgroups to a CU.  A consumer that waits on flags must
-// never hold a CU its producer still needs, so the engine pairs two launches only where both fit (mvq_kernel_regs): every
-// single-format instantiation stays under half the registers; the two mixed-format ones do not and run unpaired.
-template <uint32_t MASK>
-__global__ void __launch_bounds__(kWaves * 64) mvq_flag_kernel(uint32_t wbpack, uint32_t geom, uint32_t geom2, uint32_t L_red_floats,
-                                                               uint32_t lds_red_off, const MvLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  mvq_body<MASK, true, false, true>(blockIdx.x, wbpack, geom, geom2, L_red_floats, lds_red_off, L, smem8);
-}
-using MvqKernelFn = void (*)(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const MvLaunch);
-template <uint32_t MASK, bool ATTN, bool FLAG>
-static constexpr MvqKernelFn mvq_fn() {
-  if constexpr (!FLAG) return &mvq_kernel<MASK, ATTN>;
-  else return &mvq_flag_kernel<MASK>;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Chained ops: several dependent mat-vecs (wo -> gate/up -> down) in ONE launch, the workgroups staying resident, with
-// a grid barrier between ops instead of a kernel boundary (measured: 2.6 us per XCD-hierarchical barrier with hand-off
-// vs ~4.7 us per graph node; tools/probes/grid_barrier_probe.hip).  MEASURED on Llama-3-8B: 553 tokens/s chained vs 604
-// launch-per-op — the hand-off (write-through stores drained before the barrier, agent-scope loads of the XQ records that
-// every workgroup needs, which therefore miss the XCD's L2) costs more than the kernel boundary it replaces; an L2
-// invalidate (buffer_inv sc1) after the barrier instead of sc1 loads was far worse (374).  Touching the next op's
-// first weight tiles into L2 before the barrier (LDS-DMA loads, stores drained first) made it slower still (502): the burst
-// competes with the barrier's own traffic and with the agent-scope x loads behind it.  Kept behind LGH_FLAG_CHAIN_FFN,
-// bit-identical to the default, as the starting point for a design whose hand-off is cheaper than a kernel boundary.  Every CU holds exactly one workgroup (the launch is
-// kNumCU workgroups and each needs more than half a CU's registers), so all of them are resident and the barrier cannot
-// deadlock; its spins are bounded anyway and a timeout raises a flag the host checks.
-//   sync words: [0] launch base (barriers completed by earlier launches)  [32] top  [64 + 32x] count of XCD x
-//               [320 + 32x] generation of XCD x   [576] error
-// ------------------------------------------------------------------------------------------------
-constexpr unsigned kChainSpinLimit = 1u << 22;
-
-__device__ __forceinline__ unsigned chain_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// (the caller has drained its write-through stores)
-__device__ __forceinline__ void chain_barrier(unsigned* sync, unsigned round, unsigned n_wg_launch) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned x = blockIdx.x & 7u, per = (n_wg_launch + 7u - x) >> 3;   // workgroups with blockIdx % 8 == x
-    const unsigned old = __hip_atomic_fetch_add(&sync[64 + 32 * x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    if (old + 1 == (round + 1) * per) {   // last arrival of this XCD group: meet the other groups, then release the group
-      __hip_atomic_fetch_add(&sync[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned groups = n_wg_launch < 8u ? n_wg_launch : 8u;
-      while (chain_ld(&sync[32]) < (round + 1) * groups) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kChainSpinLimit) { sync[576] = 1; break; }
-      }
-      __hip_atomic_store(&sync[320 + 32 * x], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      while (chain_ld(&sync[320 + 32 * x]) < round + 1) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kChainSpinLimit) { sync[576] = 2; break; }
-      }
-    }
-  }
-  __syncthreads();
-}
-
-template <uint32_t MASK>
-__global__ void __launch_bounds__(kWaves * 64) mvq_chain_kernel(const MvLaunch* __restrict__ ops, const MvChainOp* __restrict__ geo,
-                                                                int nops, unsigned* sync) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  const unsigned base = chain_ld(&sync[0]);   // same value in every workgroup: the previous launch has completed
-  for (int i = 0; i < nops; i++) {
-    const MvChainOp g = geo[i];
-    if (blockIdx.x < g.n_wg) mvq_body<MASK, true>(blockIdx.x, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8);
-    if (i + 1 < nops) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's write-through stores have reached the coherence point
-      chain_barrier(sync, base + (unsigned)i, gridDim.x);
-    }
-  }
-  // (no barrier after the last op: the kernel boundary orders it.)  Workgroup 0 has left the last barrier, so every
-  // workgroup has read `base`: advance it for the next launch.
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&sync[0], base + (unsigned)(nops - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Flow launch: several dependent mat-vecs (wo -> gate/up -> down) in ONE launch whose workgroups are SPLIT between the ops
-// (block ranges, in op order) instead of shared by them: the consumers' workgroups start with the launch, put their first
-// weight tiles in flight and wait for their producer's records by hand-off counter (handoff.h) — no kernel boundary and no
-// grid barrier between the ops, and a consumer's ramp-up hides under its producer's streaming.  Every instantiation of the
-// body stays under half the registers (two workgroups per CU).  Workgroups are dispatched in block order, so a producer's
-// workgroups are always placed before the consumers that wait for them: no wait can starve its producer of a CU.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kWaves * 64) mvq_flow_kernel(const MvLaunch* __restrict__ ops, const MvChainOp* __restrict__ geo, int nops) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
-  uint32_t bid = blockIdx.x;
-  int i = 0;
-  for (; i + 1 < nops; i++) {
-    const uint32_t n = geo[i].n_wg;
-    if (bid < n) break;
-    bid -= n;
-  }
-  const MvChainOp g = geo[i];
-  switch (g.pad0) {   // the op's format
-    case 1u << F_Q4K: mvq_body<(1u << F_Q4K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
-    case 1u << F_Q6K: mvq_body<(1u << F_Q6K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
-    case 1u << F_Q5K: mvq_body<(1u << F_Q5K), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
-    case 1u << F_Q80: mvq_body<(1u << F_Q80), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
-    default: mvq_body<(1u << F_Q40), true, false, true, true>(bid, g.wbpack, g.geom, g.geom2, g.red_floats, g.lds_red_off, ops[i], smem8); break;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -827,22 +618,17 @@ size_t mvq_lds_bytes(uint32_t nwaves, uint32_t nbw, uint32_t red_floats) {
   return (size_t)mvq_red_offset(nwaves, nbw) + (size_t)red_floats * 4 + 64;
 }
 
-template <uint32_t MASK, bool ATTN = false, bool FLAG = false>
+template <uint32_t MASK>
 static hipError_t mvq_go(const MvLaunch& L, uint32_t n_wg, uint32_t threads, size_t lds, hipStream_t st, uint32_t wbpack, uint32_t geom,
                          uint32_t geom2, uint32_t red_off) {
   static bool attr_set[64] = {};
-  constexpr MvqKernelFn fn = mvq_fn<MASK, ATTN, FLAG>();
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(fn), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL(fn, dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_kernel<MASK>), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL((mvq_kernel<MASK>), dim3(n_wg), dim3(threads), lds, st, wbpack, geom, geom2, L.red_floats, red_off, L);
   return hipGetLastError();
 }
 
-// registers per lane of the instantiation a launch with this format mask takes (flag-ordered or not): what the engine
-// checks before it lets two launches run side by side
-int mvq_kernel_regs(uint32_t mask, bool flag);
-
 // launch-uniform geometry of one op, packed for the kernel; returns the format mask (0 = not launchable)
-uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp* g, size_t* lds_out) {
+uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvGeom* g, size_t* lds_out) {
   const MvSeg& S0 = L.seg[0];
   const size_t lds = mvq_lds_bytes(threads / 64, S0.units, L.red_floats);
   if (lds > 160 * 1024 || threads == 0 || threads > kWaves * 64 || n_wg == 0 || L.nseg < 1 || L.nseg > 3) return 0;
@@ -860,42 +646,21 @@ uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvChainOp*
   }
   const uint32_t Rg = S0.rows_per_wg / 16 / S0.G;
   if (S0.T > 255 || S0.G > 255 || S0.units > 0x3FFF || S0.nblk > 0xFFFF || Rg > 0xFFFF) return 0;
-  if (L.attn_acc && (L.nseg != 1 || S0.npass != 1 || L.do_norm || L.attn_splits == 0 || L.attn_splits > kMergeMaxSplits)) return 0;
   g->wbpack = (L.nseg > 1 ? L.seg[1].wg_begin : 0xFFFFu) | (L.nseg > 2 ? L.seg[2].wg_begin : 0xFFFFu) << 16;
-  g->geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u) | (L.attn_acc ? 1u << 30 : 0u);
+  g->geom = S0.T | S0.G << 8 | S0.units << 16 | (L.do_norm ? 1u << 31 : 0u);
   g->geom2 = S0.nblk | Rg << 16;
   g->red_floats = L.red_floats;
   g->lds_red_off = mvq_red_offset(threads / 64, S0.units);
   g->n_wg = n_wg;
-  g->pad0 = g->pad1 = 0;
   *lds_out = lds;
   return mask;
 }
 
 hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStream_t st) {
-  MvChainOp g;
+  MvGeom g;
   size_t lds = 0;
   const uint32_t mask = mvq_pack(L, n_wg, threads, &g, &lds);
   const uint32_t wbpack = g.wbpack, geom = g.geom, geom2 = g.geom2, red_off = g.lds_red_off;
-  if (L.attn_acc) {   // the output projection fed from the attention's split partials: single-format instantiations
-    switch (mask) {
-      case 1u << F_Q4K: return mvq_go<(1u << F_Q4K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-      case 1u << F_Q6K: return mvq_go<(1u << F_Q6K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-      case 1u << F_Q5K: return mvq_go<(1u << F_Q5K), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-      case 1u << F_Q80: return mvq_go<(1u << F_Q80), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-      case 1u << F_Q40: return mvq_go<(1u << F_Q40), true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off);
-      default: return hipErrorInvalidValue;
-    }
-  }
-  if (L.flag_sync) {   // flag-ordered launch (handoff.h)
-#define LGH_MVQ_FCASE(M) case M: return mvq_go<M, false, true>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
-    switch (mask) {
-      LGH_MVQ_FCASE(1u << F_Q4K); LGH_MVQ_FCASE(1u << F_Q6K); LGH_MVQ_FCASE(1u << F_Q5K); LGH_MVQ_FCASE(1u << F_Q80); LGH_MVQ_FCASE(1u << F_Q40);
-      LGH_MVQ_FCASE((1u << F_Q4K) | (1u << F_Q6K)); LGH_MVQ_FCASE((1u << F_Q5K) | (1u << F_Q6K));
-      default: return hipErrorInvalidValue;
-    }
-#undef LGH_MVQ_FCASE
-  }
 #define LGH_MVQ_CASE(M) case M: return mvq_go<M>(L, n_wg, threads, lds, st, wbpack, geom, geom2, red_off)
   switch (mask) {   // single formats and the two mixes of the "_M" quantisations (fused QKV: V in Q6_K)
     LGH_MVQ_CASE(1u << F_Q4K); LGH_MVQ_CASE(1u << F_Q6K); LGH_MVQ_CASE(1u << F_Q5K); LGH_MVQ_CASE(1u << F_Q80); LGH_MVQ_CASE(1u << F_Q40);
@@ -903,20 +668,6 @@ hipError_t mvq_launch(const MvLaunch& L, uint32_t n_wg, uint32_t threads, hipStr
     default: return hipErrorInvalidValue;   // other mixes: the caller launches one format at a time
   }
 #undef LGH_MVQ_CASE
-}
-
-int mvq_kernel_regs(uint32_t mask, bool flag) {
-  hipFuncAttributes a{};
-  const void* fn = nullptr;
-#define LGH_MVQ_RCASE(M) case M: fn = flag ? reinterpret_cast<const void*>(mvq_fn<M, false, true>()) : reinterpret_cast<const void*>(mvq_fn<M, false, false>()); break
-  switch (mask) {
-    LGH_MVQ_RCASE(1u << F_Q4K); LGH_MVQ_RCASE(1u << F_Q6K); LGH_MVQ_RCASE(1u << F_Q5K); LGH_MVQ_RCASE(1u << F_Q80); LGH_MVQ_RCASE(1u << F_Q40);
-    LGH_MVQ_RCASE((1u << F_Q4K) | (1u << F_Q6K)); LGH_MVQ_RCASE((1u << F_Q5K) | (1u << F_Q6K));
-    default: return -1;
-  }
-#undef LGH_MVQ_RCASE
-  if (hipFuncGetAttributes(&a, fn) != hipSuccess) return -1;
-  return a.numRegs;
 }
 
 uint32_t mvq_tile_bytes(int dev_type) {
@@ -932,74 +683,6 @@ uint32_t mvq_format_mask(const MvLaunch& L) {
     m |= 1u << f;
   }
   return m;
-}
-
-// ---- chains
-hipError_t mvq_chain_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h) {
-  if (nops < 2 || nops > kChainMaxOps) return hipErrorInvalidValue;
-  h->nops = nops;
-  h->mask = 0;
-  h->lds = 0;
-  h->threads = 0;
-  for (int i = 0; i < nops; i++) {
-    size_t lds = 0;
-    const uint32_t m = mvq_pack(Ls[i], n_wg[i], threads[i], &h->geo[i], &lds);
-    if (!m || n_wg[i] > (uint32_t)kNumCU) return hipErrorInvalidValue;
-    h->op[i] = Ls[i];
-    h->mask |= m;
-    h->lds = std::max(h->lds, lds);
-    h->threads = std::max(h->threads, threads[i]);
-  }
-  // instantiated chains: Q4_K, and Q4_K + Q6_K (the FFN of the Q4_K_M mix)
-  if (h->mask != (1u << F_Q4K) && h->mask != ((1u << F_Q4K) | (1u << F_Q6K)) && h->mask != (1u << F_Q6K)) return hipErrorInvalidValue;
-  for (int i = 0; i < nops; i++)
-    if (threads[i] != h->threads) return hipErrorInvalidValue;   // one launch geometry for all ops
-  return hipSuccess;
-}
-
-// ---- flow launches
-hipError_t mvq_flow_prepare(const MvLaunch* Ls, const uint32_t* n_wg, const uint32_t* threads, int nops, MvChainHost* h) {
-  if (nops < 2 || nops > kChainMaxOps) return hipErrorInvalidValue;
-  h->nops = nops;
-  h->mask = 0;
-  h->lds = 0;
-  h->threads = threads[0];
-  uint32_t total = 0;
-  for (int i = 0; i < nops; i++) {
-    size_t lds = 0;
-    const uint32_t m = mvq_pack(Ls[i], n_wg[i], threads[i], &h->geo[i], &lds);
-    // one format per op, one launch geometry; no op with more workgroups than CUs (two workgroups fit on a CU)
-    if (!m || (m & (m - 1)) || n_wg[i] > (uint32_t)kNumCU || threads[i] != h->threads || !Ls[i].flag_sync) return hipErrorInvalidValue;
-    h->geo[i].pad0 = m;
-    h->op[i] = Ls[i];
-    h->mask |= m;
-    h->lds = std::max(h->lds, lds);
-    total += n_wg[i];
-  }
-  if (h->lds * 2 > 160 * 1024) return hipErrorInvalidValue;   // (a consumer's workgroup shares its CU with a producer's)
-  h->geo[0].pad1 = total;
-  return hipSuccess;
-}
-
-hipError_t mvq_flow_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, hipStream_t st) {
-  static bool attr_set[64] = {};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_flow_kernel), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL(mvq_flow_kernel, dim3(h.geo[0].pad1), dim3(h.threads), h.lds, st, dev_ops, dev_geo, h.nops);
-  return hipGetLastError();
-}
-
-template <uint32_t MASK>
-static hipError_t chain_go(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st) {
-  static bool attr_set[64] = {};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvq_chain_kernel<MASK>), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL((mvq_chain_kernel<MASK>), dim3(kNumCU), dim3(h.threads), h.lds, st, dev_ops, dev_geo, h.nops, sync);
-  return hipGetLastError();
-}
-
-hipError_t mvq_chain_launch(const MvChainHost& h, const MvLaunch* dev_ops, const MvChainOp* dev_geo, unsigned* sync, hipStream_t st) {
-  if (h.mask == (1u << F_Q4K)) return chain_go<(1u << F_Q4K)>(h, dev_ops, dev_geo, sync, st);
-  if (h.mask == (1u << F_Q6K)) return chain_go<(1u << F_Q6K)>(h, dev_ops, dev_geo, sync, st);
-  return chain_go<((1u << F_Q4K) | (1u << F_Q6K))>(h, dev_ops, dev_geo, sync, st);
 }
 
 }  // namespace lgh

@@ -249,15 +249,14 @@ hipError_t kv_store_launch(const float* k, const float* v, float* kcache, float*
 }
 
 // pipeline stages without an embedding open the token here
-__global__ void advance_kernel(int* state, int bump_epoch) {
+__global__ void advance_kernel(int* state) {
   int p = state[ST_NEXT];
   state[ST_POS] = p;
   state[ST_NEXT] = p + 1;
-  if (bump_epoch) state[ST_EPOCH] += 1;
 }
 
-hipError_t advance_launch(int* state, hipStream_t st, int bump_epoch) {
-  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, state, bump_epoch);
+hipError_t advance_launch(int* state, hipStream_t st) {
+  hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, state);
   return hipGetLastError();
 }
 

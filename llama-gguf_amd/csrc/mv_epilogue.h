@@ -15,13 +15,12 @@ struct MvEpiPre { float a, b; bool valid; };
 
 // The residual element: issued first thing (one load, older than everything else in the wave's queue).  `epi` and
 // `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
-template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, const float* xq_nw, uint32_t n_rows, uint32_t wg,
                                                            uint32_t rows_per_wg, MvEpiPre& pre, uint32_t tid = threadIdx.x) {
   if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
     const uint32_t t = tid, row = wg * rows_per_wg + t;
     if (t < rows_per_wg && row < n_rows) {
-      pre.a = coh_load<COH>(resid + row);   // the residual stream may have been written earlier in this very launch
+      pre.a = resid[row];
       pre.b = xq_nw ? xq_nw[row] : 1.0f;   // the next consumer's norm weight, for the XQ image of the output
       pre.valid = true;
     }
@@ -46,7 +45,6 @@ __device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos,
 
 // Per-row epilogue, one thread per row (or per row pair for RoPE)
 // `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
-template <bool COH = false>
 __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
                                             const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false},
                                             uint32_t tid = threadIdx.x) {
@@ -74,12 +72,12 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     const float s = pre.valid ? pre.b : L.rope_cs[((size_t)pos * half + i) * 2 + 1];
     float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
     if (S.epi == EPI_ROPE_Q) {
-      coh_store<COH>(S.out + row, y0);
-      coh_store<COH>(S.out + row + 1, y1);
+      S.out[row] = y0;
+      S.out[row + 1] = y1;
     } else {
       float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
-      coh_store<COH>(dst, y0);
-      coh_store<COH>(dst + 1, y1);
+      dst[0] = y0;
+      dst[1] = y1;
     }
     return;
   }
@@ -91,18 +89,18 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   float outv = 0.0f;        // the value written to out[row] by the epilogues that can also leave an XQ image
   bool has_out = false;
   switch (S.epi) {
-    case EPI_STORE: outv = v0; coh_store<COH>(S.out + row, outv); has_out = true; break;
-    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : coh_load<COH>(S.resid + row)); coh_store<COH>(S.out + row, outv); has_out = true; break;
+    case EPI_STORE: outv = v0; S.out[row] = outv; has_out = true; break;
+    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : S.resid[row]); S.out[row] = outv; has_out = true; break;
     case EPI_SWIGLU: {
       float up = rowval(1, t);
       outv = silu_f(v0) * up;
-      coh_store<COH>(S.out + row, outv);
+      S.out[row] = outv;
       has_out = true;
       break;
     }
     case EPI_V_CACHE: {
       const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
-      coh_store<COH>(S.out + ((size_t)(row / d) * S.max_seq + pos) * d + (row % d), v0);
+      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
       break;
     }
     case EPI_MOE_SWIGLU: {
@@ -133,7 +131,7 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   if (xq && has_out) {
     const float* nw = S.xq_nw;
     const float w = !nw ? 1.0f : (pre.valid && (S.epi == EPI_RESID || S.epi == EPI_MOE_DOWN)) ? pre.b : nw[row];
-    xq_store_chunk<COH>(xq, row >> 4, outv * w, S.xq_ssq, outv, tid);
+    xq_store_chunk(xq, row >> 4, outv * w, S.xq_ssq, outv, tid);
   }
 }
 

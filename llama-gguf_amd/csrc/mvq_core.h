@@ -164,4 +164,135 @@ __device__ __forceinline__ void mvq_consume_tile(int fmt, const RawT16& r, const
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same arithmetic in two halves, for the multi-sequence mat-vec (matvec_batch.hip): a weight tile is unpacked ONCE
+// (mvq_unpack_tile: the B operands of its four MFMAs + its scales) and then multiplied with the XQ operands of every
+// sequence (mvq_mac_tile).  mvq_mac_tile(unpack(r), load(rec)) performs, per format, exactly the floating-point
+// operations of mvq_consume_tile(r, rec) in the same order — that is what makes a batched step bit-identical to the
+// single-sequence engine (tests/test_gpu_batch.py).
+// ------------------------------------------------------------------------------------------------
+struct XqOps { i32x4 a[4]; f32x4 xs, sx; };   // the A operands of a block's four MFMAs (zero outside the lane's own chunk), x sums, x scales
+
+// this lane's operands out of one XQ record (LDS or global memory)
+__device__ __forceinline__ void xq_load_ops(const uint8_t* rec, uint32_t lane, XqOps& o) {
+  const uint32_t n = lane & 15, c = lane >> 4;
+  const bool a_valid = (n >> 2) == c;
+  const uint32_t a_off = (c >> 1) * 128 + (n & 3) * 32 + (c & 1) * 16;
+#pragma unroll
+  for (int pp = 0; pp < 4; pp++) {
+    i32x4 t = {0, 0, 0, 0};
+    if (a_valid) t = *reinterpret_cast<const i32x4*>(rec + pp * 256 + a_off);
+    o.a[pp] = t;
+  }
+  o.xs = *reinterpret_cast<const f32x4*>(rec + kXqXs16 + c * 16);
+  o.sx = *reinterpret_cast<const f32x4*>(rec + kXqSx16 + c * 16);
+}
+
+struct TileOps {
+  i32x4 bw[4];      // B operand of step pp
+  float f[4];       // per step: Q4_K/Q5_K sub-block scale, Q6_K int8 scale, Q8_0/Q4_0 block d
+  float g[4];       // Q4_K/Q5_K: sub-block min
+  float dd, dmin;   // Q4_K/Q5_K: d, dmin; Q6_K: d
+};
+
+template <uint32_t MASK>
+__device__ __forceinline__ void mvq_unpack_tile(int fmt, const RawT16& r, uint32_t lane, TileOps& t) {
+  const uint32_t n = lane & 15, c = lane >> 4;
+  auto is = [&](int f) { return mvq_is<MASK>(fmt, f); };
+  if (is(F_Q6K)) {
+    const uint32_t s8 = c * 8;
+    const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+      const uint32_t H = pp == 0 ? r.q[2].x : pp == 1 ? r.q[2].y : pp == 2 ? r.q[2].z : r.q[2].w;
+      t.bw[pp].x = (int)((N0 & 0x0F0F0F0Fu) | ((H & 0x03030303u) << 4));
+      t.bw[pp].y = (int)(((N0 >> 4) & 0x0F0F0F0Fu) | (((H >> 2) & 0x03030303u) << 4));
+      t.bw[pp].z = (int)((N1 & 0x0F0F0F0Fu) | (((H >> 4) & 0x03030303u) << 4));
+      t.bw[pp].w = (int)(((N1 >> 4) & 0x0F0F0F0Fu) | (((H >> 6) & 0x03030303u) << 4));
+      t.f[pp] = (float)(int)__builtin_amdgcn_sbfe((int)hdw[pp], s8, 8);
+      t.g[pp] = 0.0f;
+    }
+    const uint32_t dh = (n & 1) ? r.q[3].x >> 16 : r.q[3].x & 0xFFFFu;
+    t.dd = h2f(dh);
+    t.dmin = 0.0f;
+  } else if (is(F_Q80) || is(F_Q40)) {
+    const uint32_t hdw[4] = {r.hd.x, r.hd.y, r.hd.z, r.hd.w};
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      if (is(F_Q80)) {
+        t.bw[pp].x = (int)r.q[pp].x; t.bw[pp].y = (int)r.q[pp].y; t.bw[pp].z = (int)r.q[pp].z; t.bw[pp].w = (int)r.q[pp].w;
+      } else {
+        const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+        t.bw[pp].x = (int)(N0 & 0x0F0F0F0Fu);
+        t.bw[pp].y = (int)((N0 >> 4) & 0x0F0F0F0Fu);
+        t.bw[pp].z = (int)(N1 & 0x0F0F0F0Fu);
+        t.bw[pp].w = (int)((N1 >> 4) & 0x0F0F0F0Fu);
+      }
+      t.f[pp] = h2f((c >> 1) ? hdw[pp] >> 16 : hdw[pp] & 0xFFFFu);
+      t.g[pp] = 0.0f;
+    }
+    t.dd = t.dmin = 0.0f;
+  } else {
+    const uint32_t s8 = (c >> 1) * 8;
+    const uint32_t a = (r.hd.y >> s8) & 0x00FF00FFu, bq = (r.hd.z >> s8) & 0x00FF00FFu, cq = (r.hd.w >> s8) & 0x00FF00FFu;
+    const uint32_t sc01 = a & 0x003F003Fu, mn01 = bq & 0x003F003Fu;
+    const uint32_t sc23 = (cq & 0x000F000Fu) | ((a >> 2) & 0x00300030u);
+    const uint32_t mn23 = ((cq >> 4) & 0x000F000Fu) | ((bq >> 2) & 0x00300030u);
+    t.f[0] = ub0(sc01); t.f[1] = ub2(sc01); t.f[2] = ub0(sc23); t.f[3] = ub2(sc23);
+    t.g[0] = ub0(mn01); t.g[1] = ub2(mn01); t.g[2] = ub0(mn23); t.g[3] = ub2(mn23);
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      const uint32_t N0 = (pp & 1) ? r.q[pp >> 1].z : r.q[pp >> 1].x, N1 = (pp & 1) ? r.q[pp >> 1].w : r.q[pp >> 1].y;
+      t.bw[pp].x = (int)(N0 & 0x0F0F0F0Fu);
+      t.bw[pp].y = (int)((N0 >> 4) & 0x0F0F0F0Fu);
+      t.bw[pp].z = (int)(N1 & 0x0F0F0F0Fu);
+      t.bw[pp].w = (int)((N1 >> 4) & 0x0F0F0F0Fu);
+      if (is(F_Q5K)) {
+        const uint32_t H = ((pp >> 1) ? r.q[2].y : r.q[2].x) >> (4 * (pp & 1));
+        t.bw[pp].x |= (int)((H & 0x01010101u) << 4);
+        t.bw[pp].y |= (int)(((H >> 1) & 0x01010101u) << 4);
+        t.bw[pp].z |= (int)(((H >> 2) & 0x01010101u) << 4);
+        t.bw[pp].w |= (int)(((H >> 3) & 0x01010101u) << 4);
+      }
+    }
+    t.dd = h2f(r.hd.x & 0xFFFFu);
+    t.dmin = h2f(r.hd.x >> 16);
+  }
+}
+
+template <uint32_t MASK>
+__device__ __forceinline__ void mvq_mac_tile(int fmt, const TileOps& t, const XqOps& o, float& acc) {
+  auto is = [&](int f) { return mvq_is<MASK>(fmt, f); };
+  const i32x4 zero = {0, 0, 0, 0};
+  float V[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; pp++) {
+    const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.a[pp], t.bw[pp], zero, 0, 0, 0);
+    const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
+    V[pp] = __builtin_fmaf(hi, 65536.0f, lo);
+  }
+  if (is(F_Q6K)) {
+    float s1 = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) s1 = __builtin_fmaf(t.f[pp], __builtin_fmaf(o.sx[pp], V[pp], -32.0f * o.xs[pp]), s1);
+    acc = __builtin_fmaf(t.dd, s1, acc);
+  } else if (is(F_Q80) || is(F_Q40)) {
+    float s1 = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++)
+      s1 = __builtin_fmaf(t.f[pp], is(F_Q40) ? __builtin_fmaf(o.sx[pp], V[pp], -8.0f * o.xs[pp]) : o.sx[pp] * V[pp], s1);
+    acc += s1;
+  } else {
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int pp = 0; pp < 4; pp++) {
+      s1 = __builtin_fmaf(t.f[pp] * o.sx[pp], V[pp], s1);
+      s2 = __builtin_fmaf(t.g[pp], o.xs[pp], s2);
+    }
+    acc += t.dd * s1 - t.dmin * s2;
+  }
+}
+
 }  // namespace lgh

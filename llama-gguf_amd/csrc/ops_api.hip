@@ -13,10 +13,8 @@ using namespace lgh;
 #include <algorithm>
 
 #ifdef LGH_STAMPS
-namespace lgh { hipError_t ptok_read_stamps(unsigned long long* host, size_t n); }
 namespace lgh { hipError_t pf_read_stamps(unsigned long long* host, size_t n); }
 extern "C" int lgh_debug_pf_stamps(unsigned long long* out, size_t n) { return lgh::pf_read_stamps(out, n) == hipSuccess ? 0 : 10; }
-extern "C" int lgh_debug_pt_stamps(unsigned long long* out, size_t n) { return lgh::ptok_read_stamps(out, n) == hipSuccess ? 0 : 10; }
 namespace lgh { hipError_t mv_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_stamps(unsigned long long* host, size_t n); hipError_t mvq_read_wave_stamps(unsigned long long* host, size_t n); hipError_t mvq_spans(unsigned long long* host, int reset); }
 #include <cstdio>
 #include "timeline.h"

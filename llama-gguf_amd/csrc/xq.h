@@ -34,23 +34,6 @@ __host__ __device__ inline size_t xq_bytes(size_t k) { return (k + 255) / 256 * 
 // `chunk` (global index, element / 16) of a vector; `v` is this lane's element (already multiplied by the norm weight
 // when the consumer normalises).  Writes the chunk's 64 limb bytes, its sum and its scale.
 // With `ssq_part` the chunk's sum of `raw`^2 (the un-normalised values) goes to ssq_part[chunk].
-// COH: agent-scope (write-through) stores, for a consumer in the SAME launch on another XCD (chained ops, matvec_mfma.hip).
-template <bool COH>
-__device__ __forceinline__ void coh_store(uint32_t* p, uint32_t v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ void coh_store(float* p, float v) {
-  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-template <bool COH>
-__device__ __forceinline__ float coh_load(const float* p) {
-  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
-template <bool COH = false>
 __device__ __forceinline__ void xq_store_chunk(uint8_t* xq, uint32_t chunk, float v, float* ssq_part = nullptr, float raw = 0.0f,
                                                uint32_t tid = threadIdx.x) {
   const uint32_t l16 = tid & 15;
@@ -76,12 +59,12 @@ __device__ __forceinline__ void xq_store_chunk(uint8_t* xq, uint32_t chunk, floa
   const uint32_t word = __builtin_amdgcn_perm(hi, lo, 0x05040100u);
   const uint32_t blk = chunk >> 4, j = chunk & 15, g = j >> 1, i = 3 - q;
   uint8_t* rec = xq + (size_t)blk * kXqRecord;
-  coh_store<COH>(reinterpret_cast<uint32_t*>(rec + (g * 4 + i) * 32 + (j & 1) * 16 + Q * 4), word);
+  *reinterpret_cast<uint32_t*>(rec + (g * 4 + i) * 32 + (j & 1) * 16 + Q * 4) = word;
   if (l16 == 0) {
     const uint32_t slot = (j & 3) * 4 + (j >> 2);
-    coh_store<COH>(reinterpret_cast<float*>(rec + kXqXs16 + slot * 4), sum);
-    coh_store<COH>(reinterpret_cast<float*>(rec + kXqSx16 + slot * 4), __uint_as_float((e + 1u - 30u) << 23));   // s * 2^-30, s = 2^(e-126)
-    if (ssq_part) coh_store<COH>(ssq_part + chunk, sq);
+    *reinterpret_cast<float*>(rec + kXqXs16 + slot * 4) = sum;
+    *reinterpret_cast<float*>(rec + kXqSx16 + slot * 4) = __uint_as_float((e + 1u - 30u) << 23);   // s * 2^-30, s = 2^(e-126)
+    if (ssq_part) ssq_part[chunk] = sq;
   }
 }
 

@@ -44,17 +44,13 @@ SYM_COUNT = 24
 SYM_NAMES = ("lgh::mv_kernel<1u, 1024>", "lgh::mv_kernel<8u, 1024>", "lgh::mv_kernel<16u, 1024>",
              "lgh::mv_kernel<2u, 768>", "lgh::mv_kernel<4u, 512>", "lgh::mv_kernel<5u, 512>", "lgh::mv_kernel<6u, 512>",
              "lgh::mv_kernel<31u, 512>", "lgh::f32_matvec_kernel", "lgh::attn_partial_kernel", "lgh::attn_combine_kernel",
-             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u, false>", "lgh::mvq_kernel<2u, false>", "lgh::mvq_kernel<3u, false>", "lgh::mvq_kernel<4u, false>",
-             "lgh::mvq_kernel<8u, false>", "lgh::ptok_kernel")
+             "lgh::embed_kernel", "lgh::argmax_stage1+2", "lgh::moe_router_kernel", "other", "lgh::mvq_kernel<1u>", "lgh::mvq_kernel<2u>", "lgh::mvq_kernel<3u>", "lgh::mvq_kernel<4u>",
+             "lgh::mvq_kernel<8u>", "unused")
 FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 KV_F32, KV_INT8, KV_FP8_E4M3, KV_FP8_E5M2 = 0, 1, 2, 3   # lgh_model_desc.kv_cache_type (the reference's KVCacheFormat)
-FLAG_PERSISTENT = 8   # decode with the persistent token kernel (one launch per token; opt-in: measured slower; LGH_PERSISTENT=1 sets it too)
-FLAG_OVERLAP = 32      # flag-ordered mat-vec launches on two streams of the token graph (opt-in: measured slower; LGH_OVERLAP=1 sets it too)
-FLAG_FLOW_FFN = 64     # wo | gate-up | down as one launch ordered by hand-off counters (opt-in: measured slower; LGH_FLOW=1 sets it too)
-FLAG_ATTN_FUSED = 128  # split attention merged by the last-arriving split, no combine launch (opt-in: measured slower; LGH_ATTN_FUSED=1 sets it too)
 FLAG_KV_INT8 = 16   # KV cache in the reference's int8 format (kv_quantized.rs: int8 rows + one scale per head and position)
-FLAG_CHAIN_FFN = 2   # dense layers: wo -> gate/up -> down as one launch with grid barriers (LGH_CHAIN_FFN=1 sets it too)
+FLAG_REMOVED_MASK = 2 | 8 | 32 | 64 | 128 | (0xFF << 24)   # round-2 decode experiments, removed in round 3: lgh_create answers Unsupported
 
 
 class BackendError(RuntimeError):
@@ -192,8 +188,7 @@ class HipGpuInference:
     # -- pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>  (gpu_only.rs:426)
     @classmethod
     def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
-                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, attn_merge: int = 0,
-                   kv_cache_type: int = 0) -> "HipGpuInference":
+                   flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, kv_cache_type: int = 0) -> "HipGpuInference":
         """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
         `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
         L = load_library()
@@ -210,15 +205,8 @@ class HipGpuInference:
         d.device_id = device
         lb, le = (0, cfg.num_layers) if layer_range is None else (layer_range[0], layer_range[1])
         d.layer_begin, d.layer_end = lb, le
-        if os.environ.get("LGH_CHAIN_FFN", "") not in ("", "0"):
-            flags |= FLAG_CHAIN_FFN
-        if os.environ.get("LGH_PERSISTENT", "") not in ("", "0"):
-            flags |= FLAG_PERSISTENT
-        for env, bit in (("LGH_OVERLAP", FLAG_OVERLAP), ("LGH_FLOW", FLAG_FLOW_FFN), ("LGH_ATTN_FUSED", FLAG_ATTN_FUSED)):
-            if os.environ.get(env, "") not in ("", "0"):
-                flags |= bit
-        # attn_direct / attn_merge: 64-row units, 0 = tuned default, 255 = never
-        d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16) | ((attn_merge & 0xFF) << 24)
+        # attn_direct: 64-row units, 0 = tuned default, 255 = never
+        d.flags = flags | ((attn_splits & 0xFF) << 8) | ((attn_direct & 0xFF) << 16)
         d.kv_cache_type = int(kv_cache_type)
         _chk(L.lgh_create(C.byref(d), C.byref(self._h)), "lgh_create (is a HIP device visible?)")
         self.config, self.vocab_size, self.hidden_size = cfg, cfg.vocab_size, cfg.hidden_size

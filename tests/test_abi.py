@@ -65,6 +65,18 @@ def test_no_silent_cpu_fallback_without_device(pkg):
     assert ei.value.variant == "NotAvailable"
 
 
+def test_removed_decode_experiment_flags_are_refused(pkg):
+    """The decode structures round 2 measured slower (chained FFN, persistent token kernel, flag-ordered / flow launches,
+    self-merging attention, merge inside wo) were removed in round 3: their flag bits answer Unsupported, with or without a GPU."""
+    hb = pkg.hip_backend
+    model = pkg.SynthModel(pkg.make_config("test-dense", max_seq_len=8), mix="Q4_K")
+    for bit in (2, 8, 32, 64, 128, 1 << 24):
+        assert bit & hb.FLAG_REMOVED_MASK
+        with pytest.raises(pkg.BackendError) as ei:
+            pkg.HipGpuInference.from_model(model, 8, flags=bit)
+        assert ei.value.variant == "Unsupported", bit
+
+
 def test_product_does_not_import_the_oracle():
     """The package must never route through oracle/ (it is test infrastructure)."""
     pkg_dir = os.path.join(ROOT, "llama-gguf_amd")

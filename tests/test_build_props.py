@@ -41,35 +41,9 @@ def test_no_kernel_uses_scratch_or_spills_vgprs():
 def test_mfma_kernel_fits_two_waves_per_simd():
     usage = _usage("matvec_mfma.hip")
     mvq = {fn: u for fn, u in usage.items() if "mvq_kernel" in fn}
-    assert len(mvq) == 12   # five formats + the Q4_K/Q6_K and Q5_K/Q6_K mixes, + the five single-format ATTN instantiations
+    assert len(mvq) == 7   # five formats + the Q4_K/Q6_K and Q5_K/Q6_K mixes
     for fn, u in mvq.items():
         assert u["VGPRs"] <= 256 and u.get("Occupancy", 2) >= 2, (fn, u)
-
-
-def test_flag_ordered_instantiations_fit_two_workgroups_per_cu():
-    """A flag-ordered launch shares its CU with its producer (handoff.h): every single-format instantiation and the flow
-    kernel (wo | gate-up | down in one launch) must stay within 128 registers — four waves per SIMD, two workgroups of eight
-    waves per CU — whatever the pairing.  The two mixed-format instantiations do not; the engine never pairs them."""
-    usage = _usage("matvec_mfma.hip")
-    flag = {fn: u for fn, u in usage.items() if "mvq_flag_kernel" in fn or "mvq_flow_kernel" in fn}
-    assert len(flag) == 8   # five formats, two mixes, the flow kernel
-    small = 0
-    for fn, u in flag.items():
-        mixed = "ILj3E" in fn or "ILj6E" in fn
-        if not mixed:
-            assert u["VGPRs"] + u.get("AGPRs", 0) <= 128 and u.get("Occupancy", 4) >= 4, (fn, u)
-            small += 1
-    assert small == 6
-
-
-def test_persistent_token_kernel_has_no_scratch():
-    """The opt-in persistent token kernel keeps its tile ring, the attention state and the epilogue operands in registers
-    (a per-op opaque thread id stops the lane constants from being hoisted across the op loop, decode_persistent.hip)."""
-    usage = _usage("decode_persistent.hip")
-    pt = {fn: u for fn, u in usage.items() if "ptok_kernel" in fn}
-    assert len(pt) == 15   # three format families x five (head_dim, group) shapes
-    for fn, u in pt.items():
-        assert u.get("ScratchSize", 0) == 0 and u.get("VGPRs Spill", 0) == 0 and u["VGPRs"] <= 256, (fn, u)
 
 
 def test_prefill_gemm_keeps_its_accumulators_in_registers():

@@ -259,28 +259,6 @@ def test_full_size_llama3_8b_q4_k_m_matches_oracle(pkg, orc):
             eng.close()
 
 
-@pytest.mark.parametrize("name,mix", [("test-dense", "Q4_K_M"), ("test-dense-d128", "Q4_K_M"), ("test-dense", "Q6_K")])
-def test_chained_ffn_launch_matches_separate_launches(pkg, orc, name, mix):
-    """LGH_FLAG_CHAIN_FFN (wo -> gate/up -> down in one launch, grid barriers in between) must give exactly the logits of
-    the launch-per-op path: same kernels, same arithmetic, only the boundaries differ."""
-    cfg = pkg.make_config(name, max_seq_len=64)
-    model = pkg.SynthModel(cfg, mix=mix)
-    a = pkg.HipGpuInference.from_model(model, 64)
-    b = pkg.HipGpuInference.from_model(model, 64, flags=pkg.hip_backend.FLAG_CHAIN_FFN)
-    try:
-        toks = [5, 900, 31, 7, 7, 123]
-        for t in toks[:-1]:
-            a.prefill_token(t)
-            b.prefill_token(t)
-        la, lb = a.forward(toks[-1]), b.forward(toks[-1])
-        assert np.array_equal(la, lb)
-        ta, tb = a.decode_greedy(3, 24).tolist(), b.decode_greedy(3, 24).tolist()
-        assert ta == tb
-    finally:
-        a.close()
-        b.close()
-
-
 def test_single_launch_and_split_attention_agree_across_the_switch(pkg, orc):
     """Decode attention runs as one launch per layer up to a context threshold and as split + combine beyond it (two
     graph variants, picked by the host-side position).  One engine switches at 64 rows in mid-sequence, one never uses
@@ -469,36 +447,6 @@ def test_generic_attention_refuses_contexts_that_do_not_fit_lds(pkg):
     assert ei.value.variant == "Unsupported"
 
 
-@pytest.mark.parametrize("name,mix", [("test-dense", "Q4_K_M"), ("test-dense-d128", "Q4_K_M"), ("test-dense", "Q8_0"), ("test-dense", "Q5_K_M")])
-def test_optional_decode_paths_follow_the_oracle(pkg, orc, name, mix):
-    """Two opt-in decode structures that are kept next to the default hipGraph of one launch per op: the persistent token
-    kernel (LGH_FLAG_PERSISTENT: one launch per token, data-flow hand-offs, attention inside) and the 8-split attention whose
-    partials the output projection merges itself (attn_merge).  Same tolerances as the default path; greedy tokens identical
-    to the default path's."""
-    cfg, ref, base = _pair(pkg, orc, name, mix, max_seq=160)
-    model = pkg.SynthModel(cfg, mix=mix)
-    engs = [pkg.HipGpuInference.from_model(model, 160, flags=pkg.hip_backend.FLAG_PERSISTENT),
-            pkg.HipGpuInference.from_model(model, 160, attn_merge=2)]
-    assert engs[0].stats()["graph_nodes"] == 0
-    toks = [(29 * i + 3) % cfg.vocab_size for i in range(90)]
-    worst = [0.0, 0.0]
-    for i, t in enumerate(toks):
-        want = ref.forward([t])
-        got = [e.forward(t) for e in engs]
-        base.prefill_token(t)
-        if i in (0, 1, 2, 30, 63, 64, 65, 89):
-            for k, g in enumerate(got):
-                worst[k] = max(worst[k], float(np.abs(g - want).max()))
-                assert np.abs(g - want).max() <= _tol(want), (k, i)
-    assert engs[0].stats()["graph_nodes"] <= 3          # embedding + the token kernel (+ arg-max)
-    want = base.decode_greedy(11, 24).tolist()
-    for e in engs:
-        assert e.decode_greedy(11, 24).tolist() == want
-    print(f"{name}/{mix}: persistent max|dlogit|={worst[0]:.3e}, merged attention max|dlogit|={worst[1]:.3e}")
-    for e in engs + [base]:
-        e.close()
-
-
 @pytest.mark.parametrize("name,mix,stages", [("test-dense-d128", "Q4_K_M", 2), ("test-dense-d128", "Q4_K_M", 3), ("test-moe", "Q5_K_M", 2)])
 def test_in_library_pipeline_equals_single_context(pkg, orc, name, mix, stages):
     """lgh_pipeline_*: `stages` stage contexts in ONE process (here all on one device: the peer copy degenerates to a
@@ -603,67 +551,3 @@ def test_quantized_kv_cache_follows_the_reference_formats(pkg, orc, name, mix, n
         ref.close()
 
 
-@pytest.mark.parametrize("flag_name", ["FLAG_OVERLAP", "FLAG_FLOW_FFN"])
-@pytest.mark.parametrize("name,mix,kw", [("test-dense", "Q4_K_M", {}), ("test-dense-d128", "Q4_K_M", {}), ("test-dense", "Q6_K", {}),
-                                         ("test-dense", "Q8_0", {}), ("test-dense", "Q5_K_M", {}), ("test-dense", "Q4_0", {}),
-                                         ("llama-3-8b", "Q4_K_M", {"num_layers": 6}), ("llama-3-8b", "Q6_K", {"num_layers": 3}),
-                                         ("tinyllama-1.1b", "Q4_K_M", {"num_layers": 5})])
-def test_flag_ordered_launches_equal_the_default_graph(pkg, orc, name, mix, kw, flag_name):
-    """Two opt-in structures that replace kernel boundaries between a layer's mat-vecs by hand-off counters (handoff.h):
-    LGH_FLAG_OVERLAP runs consecutive launches side by side on two streams of the token graph, LGH_FLAG_FLOW_FFN runs
-    wo | gate-up | down as ONE launch whose workgroups are split between the ops (lgh_stats.overlapped_edges pairs per
-    token either way).  Both measured slower than the default graph and both must reproduce it bit for bit:
-    logits at every position — across the switch of the attention variant, with host-fed tokens and with 96 device-fed
-    greedy steps replayed back to back (the counters only ever grow: no reset between tokens) — and no hand-off wait may
-    run into its spin limit (it would be reported as OperationFailed).  Full-width layers of the headline model are in the
-    list because only they fill every CU with both launches of a pair (a Q6_K down projection that did not FIT beside its
-    producer deadlocked now and then before the pairing was restricted to launches that fit together)."""
-    flag = getattr(pkg.hip_backend, flag_name)
-    cfg = pkg.make_config(name, max_seq_len=224, **kw)
-    model = pkg.SynthModel(cfg, mix=mix)
-    two = pkg.HipGpuInference.from_model(model, 224, flags=flag)
-    one = pkg.HipGpuInference.from_model(model, 224)
-    try:
-        assert one.stats()["overlapped_edges"] == 0
-        n_edges = two.stats()["overlapped_edges"]
-        assert n_edges >= cfg.num_layers, (name, mix, n_edges)      # at least wo -> gate/up in every layer
-        for i in range(100):
-            t = (37 * i + 5) % cfg.vocab_size
-            a, b = two.forward(t), one.forward(t)
-            assert np.array_equal(a, b), (name, mix, i, float(np.abs(a - b).max()))
-        ta, tb = two.decode_greedy(9, 96).tolist(), one.decode_greedy(9, 96).tolist()
-        assert ta == tb
-        two.reset(); one.reset()
-        for t in (3, 1, 4, 1, 5):
-            two.prefill_token(t); one.prefill_token(t)
-        assert np.array_equal(two.forward(9), one.forward(9))
-        print(f"{name}/{mix} {flag_name}: {n_edges} hand-off pairs per token over {cfg.num_layers} layers, "
-              f"graph nodes {two.stats()['graph_nodes']} vs {one.stats()['graph_nodes']}")
-    finally:
-        two.close(); one.close()
-
-
-@pytest.mark.parametrize("name,mix,kw", [("test-dense", "Q4_K_M", {}), ("test-dense-d128", "Q4_K_M", {}), ("test-moe", "Q5_K_M", {}),
-                                         ("llama-3-8b", "Q4_K_M", {"num_layers": 3}), ("tinyllama-1.1b", "Q4_K_M", {"num_layers": 3}),
-                                         ("test-dense", "Q4_K_M", dict(num_heads=8, num_kv_heads=1, head_dim=64)),        # G = 8
-                                         ("test-dense", "Q4_K_M", dict(num_heads=6, num_kv_heads=2, head_dim=128, hidden_size=768, intermediate_size=1536))])
-def test_split_attention_merged_by_the_last_split_equals_the_combine_launch(pkg, orc, name, mix, kw):
-    """LGH_FLAG_ATTN_FUSED (opt-in, measured slower): the split kernel's last-arriving workgroup of a kv head merges the
-    partials, no combine launch.  The merge is attn_combine_kernel's arithmetic with the same lane roles, so whichever split
-    arrives last the output must equal the default two-launch form bit for bit: 200 positions (both attention variants),
-    then 100 device-fed greedy steps.  (The last case has 3 heads per kv head: no split kernel, both contexts take the generic one.)"""
-    cfg = pkg.make_config(name, max_seq_len=320, **kw)
-    model = pkg.SynthModel(cfg, mix=mix)
-    a = pkg.HipGpuInference.from_model(model, 320, flags=pkg.hip_backend.FLAG_ATTN_FUSED)
-    b = pkg.HipGpuInference.from_model(model, 320)
-    try:
-        for i in range(200):
-            t = (37 * i + 5) % cfg.vocab_size
-            x, y = a.forward(t), b.forward(t)
-            assert np.array_equal(x, y), (name, mix, i, float(np.abs(x - y).max()))
-        assert a.decode_greedy(9, 100).tolist() == b.decode_greedy(9, 100).tolist()
-        na, nb = a.stats()["graph_nodes"], b.stats()["graph_nodes"]
-        assert na <= nb
-        print(f"{name}/{mix}: graph nodes {na} (merged by the last split) vs {nb} (combine launch)")
-    finally:
-        a.close(); b.close()
