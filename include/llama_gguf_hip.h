@@ -227,6 +227,27 @@ int lgh_forward_argmax(lgh_ctx* ctx, uint32_t token_id, uint32_t* next_token);
  * tokens_out[i] = arg-max after step i.  One host sync at the end. */
 int lgh_decode_greedy(lgh_ctx* ctx, uint32_t first_token, size_t n_steps, uint32_t* tokens_out);
 
+/* ---- multi-sequence decode: the device side of BatchedEngine (src/engine_batched.rs:23-194, 200-330, 355-400) ----
+ * The reference keeps one InferenceContext (KV cache + position) per ActiveSequence (engine_batched.rs:84-100, 332-353) and every
+ * iteration of its loop calls model.forward for each active sequence in turn (236-290 -> step_sequence 355-400): B sequences read
+ * the weights B times.  Here a finalized single-stage context owns `max_batch` <= 16 SLOTS (a slot = one sequence's f32 KV caches
+ * + position), and one step feeds one token to each listed slot while reading every weight tile ONCE.  Every sequence's
+ * logits are bit-identical to what lgh_forward returns for the same token history (same arithmetic, same summation orders).
+ * Dense and MoE models whose matrices are in the matrix-core tile layouts (Q4_K / Q5_K / Q6_K / Q8_0 / Q4_0, k % 256 == 0);
+ * anything else answers LGH_UNSUPPORTED.  The single-sequence entry points keep working on the context's own cache. */
+int lgh_batch_create(lgh_ctx* ctx, uint32_t max_batch);                 /* BatchedEngineConfig::max_batch_size (engine_batched.rs:23-41) */
+int lgh_batch_reset(lgh_ctx* ctx, uint32_t slot);                       /* create_active_sequence: model.create_context (332-353); O(1) */
+size_t lgh_batch_position(lgh_ctx* ctx, uint32_t slot);                 /* ActiveSequence.ctx.position */
+/* the slot's prompt (step_sequence's first call: position == 0 -> the whole prompt, 373-379), on the batched prompt path */
+int lgh_batch_prefill(lgh_ctx* ctx, uint32_t slot, const uint32_t* tokens, size_t n);
+/* One iteration of the loop (236-290): tokens[i] goes to slot slots[i] (distinct slots, 1 <= n_seq <= max_batch).
+ * logits_out: n_seq x vocab f32 (row i = sequence i) or NULL; next_tokens: the greedy choice per sequence (last maximal index)
+ * or NULL.  InvalidArgument when a slot is full (position >= max_seq_len), nothing is changed then. */
+int lgh_forward_multi(lgh_ctx* ctx, const uint32_t* slots, const uint32_t* tokens, uint32_t n_seq, float* logits_out, uint32_t* next_tokens);
+/* n_steps greedy iterations with every sequence's token fed back on the device; tokens_out[step * n_seq + i] (or NULL).  One host
+ * synchronisation at the end (the bench's timed region for --batch). */
+int lgh_decode_greedy_multi(lgh_ctx* ctx, const uint32_t* slots, const uint32_t* first_tokens, uint32_t n_seq, size_t n_steps, uint32_t* tokens_out);
+
 const char* lgh_last_error(const lgh_ctx* ctx);
 int lgh_get_stats(lgh_ctx* ctx, lgh_stats* out);
 /* on: run eagerly with hipEvent pairs around every launch and accumulate lgh_stats.k_* */

@@ -38,11 +38,15 @@ constexpr float kNegBig = -1e30f;
 // DIRECT: one workgroup of NW = 16 waves per kv head and no second kernel: the workgroup merges its waves and writes the
 // normalised output (f32 at part_acc, XQ records at part_ml when not null) itself.  It saves one launch floor per layer
 // but pulls a kv head's whole K/V through one CU, so it only pays below ~100 rows (engine.hip: kDirectAttnDefaultKv).
-template <int D, int G, int NW, bool PF = false, bool DIRECT = false>
+// MULTI (multi-sequence decode, engine_batch.hip): blockIdx.y = sequence s of the step; its query is q + s * n_heads * D, its
+// position pos_ptr[s], its K / V the cache slot slot[s] (slot_stride floats apart), its partials the s-th block of
+// part_ml / part_acc.  Per sequence the arithmetic is the single-sequence kernel's.
+template <int D, int G, int NW, bool PF = false, bool DIRECT = false, bool MULTI = false>
 __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, uint32_t max_seq, float scale,
                                                            const int* pos_ptr, int kv_len_fixed, uint32_t n_splits,
-                                                           float* __restrict__ part_ml, float* __restrict__ part_acc) {
+                                                           float* __restrict__ part_ml, float* __restrict__ part_acc,
+                                                           const int* __restrict__ slot = nullptr, uint64_t slot_stride = 0) {
   constexpr int LPR = D / 4;       // lanes per row
   constexpr int RPW = 64 / LPR;    // rows per wave-instruction
   __shared__ float s_ml[NW][G][2];
@@ -58,6 +62,16 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
   if (PF) {
     kv_len += blockIdx.y;
     q += (size_t)blockIdx.y * gridDim.x * G * D;   // gridDim.x = kv heads (one split)
+  } else if (MULTI) {
+    const uint32_t sq = blockIdx.y;
+    uint32_t pw, sl;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pw), "=&s"(sl) : "s"(pos_ptr + sq), "s"(slot + sq) : "memory");
+    kv_len = pw + 1;
+    q += (size_t)sq * (gridDim.x / n_splits) * G * D;
+    kc += (size_t)sl * slot_stride;
+    vc += (size_t)sl * slot_stride;
+    part_ml += (size_t)sq * gridDim.x * G * 2;
+    part_acc += (size_t)sq * gridDim.x * G * D;
   } else if (pos_ptr) {
     uint32_t pw;
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
@@ -446,12 +460,20 @@ hipError_t kv_roundtrip_launch(int fmt, const float* x, uint32_t n, uint8_t* byt
 
 // out[h][dim] = sum_s acc_s * e^{m_s - m*} / sum_s l_s * e^{m_s - m*}.  Lane s of the first wave owns split s
 // (all loads of a phase are independent and in flight together: the kernel is two memory round trips long).
+template <bool MULTI>
 __global__ void __launch_bounds__(128) attn_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
                                                            uint32_t g_per_kv, uint32_t head_dim, uint32_t n_splits,
                                                            float* __restrict__ out, uint8_t* __restrict__ xq_out) {
   __shared__ float s_f[64];
   __shared__ float s_linv;
   LGH_TL_BEGIN(attn, lgh::TL_COMBINE, n_splits);
+  if (MULTI) {   // blockIdx.y = sequence: its partials, its output vector and XQ image
+    const uint32_t sq = blockIdx.y, n_heads = gridDim.x;
+    part_ml += (size_t)sq * n_heads * n_splits * 2;
+    part_acc += (size_t)sq * n_heads * n_splits * head_dim;
+    out += (size_t)sq * n_heads * head_dim;
+    if (xq_out) xq_out += (size_t)sq * xq_bytes((size_t)n_heads * head_dim);
+  }
   const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
   const size_t p0 = (size_t)kvh * n_splits * g_per_kv + g;   // split s lives at p0 + s * g_per_kv
   // every partial this thread will need is requested up front (one dim per thread: blockDim == head_dim <= 128), so the
@@ -815,7 +837,43 @@ hipError_t attn_decode_any_launch(const float* q, const float* kcache, const flo
 hipError_t attn_combine_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv,
                                uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
   if (n_kv == 0 || n_heads % n_kv || head_dim % 16 || head_dim > 128 || n_splits > 32) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(attn_combine_kernel, dim3(n_heads), dim3(head_dim > 64 ? 128 : 64), 0, st, part_ml, part_acc,
+  hipLaunchKernelGGL(attn_combine_kernel<false>, dim3(n_heads), dim3(head_dim > 64 ? 128 : 64), 0, st, part_ml, part_acc,
+                     n_heads / n_kv, head_dim, n_splits, out, xq_out);
+  return hipGetLastError();
+}
+
+// ---- multi-sequence decode (engine_batch.hip): the split attention and its merge for n_seq sequences in one launch each
+template <int D, int G>
+static hipError_t attn_multi_go(const float* q, const float* kc, const float* vc, uint32_t n_kv, uint32_t max_seq, float scale, const int* pos,
+                                const int* slot, uint64_t slot_stride, uint32_t n_seq, uint32_t n_splits, float* part_ml, float* part_acc,
+                                hipStream_t st) {
+  if (max_seq >= 2048)
+    hipLaunchKernelGGL((attn_partial_kernel<D, G, 8, false, false, true>), dim3(n_kv * n_splits, n_seq), dim3(512), 0, st, q, kc, vc, max_seq, scale,
+                       pos, 0, n_splits, part_ml, part_acc, slot, slot_stride);
+  else
+    hipLaunchKernelGGL((attn_partial_kernel<D, G, 4, false, false, true>), dim3(n_kv * n_splits, n_seq), dim3(256), 0, st, q, kc, vc, max_seq, scale,
+                       pos, 0, n_splits, part_ml, part_acc, slot, slot_stride);
+  return hipGetLastError();
+}
+
+hipError_t attn_multi_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                             uint32_t max_seq, float scale, const int* pos, const int* slot, uint64_t slot_stride, uint32_t n_seq,
+                             uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || !pos || !slot || n_seq == 0 || n_splits == 0 || n_splits > 32) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_ATTN_CASE(DD, GG) \
+  if (head_dim == DD && g == GG)  \
+    return attn_multi_go<DD, GG>(q, kcache, vcache, n_kv, max_seq, scale, pos, slot, slot_stride, n_seq, n_splits, part_ml, part_acc, st);
+  LGH_ATTN_CASE(128, 1) LGH_ATTN_CASE(128, 2) LGH_ATTN_CASE(128, 4) LGH_ATTN_CASE(128, 8)
+  LGH_ATTN_CASE(64, 1) LGH_ATTN_CASE(64, 2) LGH_ATTN_CASE(64, 4) LGH_ATTN_CASE(64, 8)
+#undef LGH_ATTN_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t attn_combine_multi_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                                     uint32_t n_splits, uint32_t n_seq, float* out, uint8_t* xq_out, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || head_dim % 16 || head_dim > 128 || n_splits > 32 || n_seq == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(attn_combine_kernel<true>, dim3(n_heads, n_seq), dim3(head_dim > 64 ? 128 : 64), 0, st, part_ml, part_acc,
                      n_heads / n_kv, head_dim, n_splits, out, xq_out);
   return hipGetLastError();
 }

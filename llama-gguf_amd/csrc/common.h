@@ -144,6 +144,23 @@ struct MvLaunch {
   MvSeg seg[3];
 };
 
+// Multi-sequence launch (matvec_batch.hip): where sequence s keeps its vectors.  The vectors named in MvLaunch / MvSeg are
+// sequence 0's; sequence s adds s times the stride below (XQ images in bytes, everything else in floats).  The K / V cache
+// epilogues write into cache slot slot[s] at position pos[s].
+constexpr int kMaxBatch = 16;
+struct MvBatch {
+  uint32_t n_seq;
+  const int* pos;             // device [n_seq]
+  const int* slot;            // device [n_seq]
+  uint64_t cache_stride;      // floats between the caches of two slots
+  uint32_t xq_stride;         // bytes between the input XQ images of consecutive sequences
+  uint32_t ssq_stride;        // floats between their sum-of-squares partials
+  uint32_t out_stride[3];     // per segment
+  uint32_t resid_stride[3];
+  uint32_t xq_out_stride[3];  // bytes
+  uint32_t ssq_out_stride[3];
+};
+
 // launch-uniform geometry of one int8-MFMA launch as the kernel takes it (mvq_pack)
 struct MvGeom { uint32_t wbpack, geom, geom2, red_floats, lds_red_off, n_wg; };
 
@@ -169,6 +186,8 @@ hipError_t hbm_read_launch(const uint8_t* buf, size_t bytes, float* sink, int nt
 uint32_t mvq_pack(const MvLaunch& L, uint32_t n_wg, uint32_t threads, MvGeom* g, size_t* lds_out);
 uint32_t mvq_format_mask(const MvLaunch& L);
 uint32_t mvq_tile_bytes(int dev_type);   // bytes of one 16-row x 256-element tile in the device layout of this type (0: not a tile16 type)
+hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint32_t threads, hipStream_t st);   // matvec_batch.hip
+size_t mvqb_lds_bytes(uint32_t n_seq, uint32_t red_floats);
 hipError_t xq_quantize_launch(const float* x, const float* nw, uint8_t* xq, float* ssq_part, uint32_t k, hipStream_t st);
 hipError_t repack_t16_launch(int dev_type, const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);
 hipError_t repack_q6k_t16_launch(const uint8_t* raw, uint8_t* dst, uint32_t n_rows, uint32_t nblk, hipStream_t st);  // LGH_SYM_MV_* of the instantiation mv_launch will pick
@@ -187,6 +206,15 @@ hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, fl
 hipError_t rms_norm_launch(const float* x, const float* w, float eps, float* out, uint32_t n, hipStream_t st);
 hipError_t rope_launch(float* q, float* k, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, const int* pos,
                        const float* rope_cs, int neox, hipStream_t st);
+// multi-sequence decode (engine_batch.hip): one launch each for the n_seq sequences of a step
+hipError_t embed_multi_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t n_seq, uint8_t* xq,
+                              const float* xq_nw, float* xq_ssq, uint32_t xq_stride, uint32_t ssq_stride, hipStream_t st);
+hipError_t argmax_multi_launch(const float* logits, uint32_t n, uint32_t n_seq, float* part_val, int* part_idx, int* next, hipStream_t st);
+hipError_t attn_multi_launch(const float* q, const float* kcache, const float* vcache, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                             uint32_t max_seq, float scale, const int* pos, const int* slot, uint64_t slot_stride, uint32_t n_seq,
+                             uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st);
+hipError_t attn_combine_multi_launch(const float* part_ml, const float* part_acc, uint32_t n_heads, uint32_t n_kv, uint32_t head_dim,
+                                     uint32_t n_splits, uint32_t n_seq, float* out, uint8_t* xq_out, hipStream_t st);
 // the rest of the per-op Backend surface (misc.hip): op = 0 add, 1 mul, 2 scale, 3 silu, 4 gelu
 hipError_t ewise_launch(int op, const float* a, const float* b, float s, float* out, uint64_t n, hipStream_t st);
 hipError_t softmax_rows_launch(const float* x, float* out, uint32_t rows, uint32_t last_dim, hipStream_t st);

@@ -182,6 +182,30 @@ hipError_t embed_launch(int src_type, const uint8_t* table, const int* token, fl
 }
 
 // rows tokens[0..m) of the table -> dst[m][hidden] (batched prompt processing, prefill.hip)
+// multi-sequence decode: blockIdx.y = sequence s; row tokens[s] -> dst + s * hidden, its XQ image and sum-of-squares partials
+// at s * their strides (the arithmetic of embed_kernel; the positions are kept by the host, engine_batch.hip)
+__global__ void __launch_bounds__(256) embed_multi_kernel(int type, const uint8_t* __restrict__ table, const int* __restrict__ tokens,
+                                                          float* __restrict__ dst, uint32_t hidden, uint8_t* __restrict__ xq,
+                                                          const float* __restrict__ xq_nw, float* __restrict__ xq_ssq, uint32_t xq_stride,
+                                                          uint32_t ssq_stride) {
+  const uint32_t sq = blockIdx.y;
+  const uint64_t row = (uint64_t)(uint32_t)tokens[sq];
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < hidden) {
+    const float v = deq_any(type, table, row * hidden + i);
+    dst[(size_t)sq * hidden + i] = v;
+    if (xq) xq_store_chunk(xq + (size_t)sq * xq_stride, i >> 4, xq_nw ? v * xq_nw[i] : v, xq_ssq ? xq_ssq + (size_t)sq * ssq_stride : nullptr, v);
+  }
+}
+
+hipError_t embed_multi_launch(int src_type, const uint8_t* table, const int* tokens, float* dst, uint32_t hidden, uint32_t n_seq, uint8_t* xq,
+                              const float* xq_nw, float* xq_ssq, uint32_t xq_stride, uint32_t ssq_stride, hipStream_t st) {
+  if (!blk_elems(src_type) || (xq && hidden % 256) || n_seq == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(embed_multi_kernel, dim3((hidden + 255) / 256, n_seq), dim3(256), 0, st, src_type, table, tokens, dst, hidden, xq, xq_nw,
+                     xq_ssq, xq_stride, ssq_stride);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) embed_batch_kernel(int type, const uint8_t* __restrict__ table, const int* __restrict__ tokens,
                                                           float* __restrict__ dst, uint32_t hidden) {
   const uint64_t row = (uint64_t)(uint32_t)tokens[blockIdx.y];

@@ -47,6 +47,22 @@ struct PfScratch {
 
 struct ProfRec { int cls; int sym; uint64_t bytes; hipEvent_t a, b; };
 
+// multi-sequence decode (engine_batch.hip): `max_batch` slots, each one sequence's KV caches and position, and the vectors of
+// up to max_batch sequences side by side ([sequence][...], sequence s of a step at s times the vector's length)
+struct BatchScratch {
+  bool ready = false;
+  uint32_t max_batch = 0, ffn = 0;
+  uint64_t cache_stride = 0;                          // floats between two slots' caches of one layer
+  float *hidden = nullptr, *xnorm = nullptr, *q = nullptr, *attn_out = nullptr, *act = nullptr, *act2 = nullptr, *logits = nullptr,
+        *part_ml = nullptr, *part_acc = nullptr, *amax_v = nullptr, *moe_w = nullptr;
+  int *amax_i = nullptr, *moe_sel = nullptr;
+  int *d_tokens = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_log = nullptr;   // the step's control words (device), the greedy token log
+  int* h_ctl = nullptr;                               // pinned staging of the control words
+  std::vector<float*> kcache, vcache;                 // per layer: [slot][kv_head][max_seq][head_dim]
+  std::vector<size_t> pos;                            // per slot: tokens in its cache
+  hipGraphExec_t graph[kMaxBatch + 1][2] = {};        // [n_seq][0 logits only, 1 + arg-max fed back]
+};
+
 }  // namespace lgh
 
 struct lgh_ctx {
@@ -84,6 +100,7 @@ struct lgh_ctx {
   std::vector<void*> allocs;  // everything hipMalloc'ed by this context
   std::vector<lgh::XqBuf> xqs;
   lgh::PfScratch pf;
+  lgh::BatchScratch batch;
   float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 
@@ -113,7 +130,13 @@ struct SegSpec {
   const float* moe_w = nullptr;
 };
 
+// the vectors the FFN half of a layer works on (one sequence's)
+struct FfnView { float* hidden; float* act; float* act2; float* xnorm; int* moe_sel; float* moe_w; };
+
 int fail(lgh_ctx* c, int status, const std::string& msg);
+int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma, lgh::MvLaunch& L, uint32_t& wg,
+                   uint32_t& threads, uint64_t& alg, uint32_t tile_cap);
+int ffn_forward(lgh_ctx* c, lgh::LayerW& Lw, const FfnView& v, const float* next_nw, bool next_mfma);
 int engine_shape_check(const lgh_model_desc& d, std::string& why);   // LGH_OK, or the status lgh_create returns and why
 int dev_alloc(lgh_ctx* c, void** p, size_t bytes);
 LayoutInfo layout_for(int src_type);

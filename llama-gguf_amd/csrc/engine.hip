@@ -238,8 +238,10 @@ void xq_stale(lgh_ctx* c, const float* f32) {
 static uint32_t g_launch_seq = 0;   // diagnostic builds: consecutive launches get consecutive span slots
 // Assembles the launch descriptor of one group of segments (and keeps the XQ bookkeeping: images this launch consumes are
 // converted here if their producer did not leave them; images it produces are marked fresh).
-static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma, MvLaunch& L,
-                          uint32_t& wg, uint32_t& threads, uint64_t& alg) {
+// `tile_cap` (multi-sequence launches, engine_batch.hip): at most that many 16-row tiles per workgroup — the partial sums of
+// every sequence of the step must fit LDS.  It changes which workgroup computes a row, never the row's arithmetic.
+int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma, MvLaunch& L,
+                   uint32_t& wg, uint32_t& threads, uint64_t& alg, uint32_t tile_cap) {
   std::memset(&L, 0, sizeof(L));
   L.nseg = nseg;
   L.k = k;
@@ -289,6 +291,14 @@ static int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const floa
     }
     if (ok && mixed)
       for (int s = 0; s < nseg; s++) force_tiles[s] = R[s];
+  }
+  if (mfma && tile_cap) {
+    for (int s = 0; s < nseg; s++) {
+      const DevWeight& W0 = *specs[s].W[0];
+      MvPlan p;
+      if (mvq_plan(W0.k, W0.n, specs[s].npass, &p, launch_rows, force_tiles[s]) != hipSuccess) continue;
+      if (p.rows_per_wg / 16 > tile_cap) force_tiles[s] = std::max(p.G, tile_cap / p.G * p.G);
+    }
   }
   for (int s = 0; s < nseg; s++) {
     const SegSpec& sp = specs[s];
@@ -375,7 +385,7 @@ static int launch_mv_group(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, 
   MvLaunch L;
   uint32_t wg, threads;
   uint64_t alg;
-  int rc = build_mv_group(c, specs, nseg, norm_w, k, mfma, L, wg, threads, alg);
+  int rc = build_mv_group(c, specs, nseg, norm_w, k, mfma, L, wg, threads, alg, 0);
   if (rc) return rc;
   if (mfma) return run_k(c, cls, mvq_symbol(L), alg, [&] { return mvq_launch(L, wg, threads, c->stream); });
   return run_k(c, cls, mv_symbol(L), alg, [&] { return mv_launch(L, wg, threads, c->stream); });
@@ -429,6 +439,81 @@ int linear_any(lgh_ctx* c, int cls, const DevWeight& W, const float* x, float* o
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// the FFN half of a layer on one sequence's vectors: FeedForward::forward (layers.rs:908-929) or MoeLayer::forward
+// (moe.rs:321-413), residual included.  The single-sequence path passes the context's own buffers; the multi-sequence path
+// (engine_batch.hip) runs MoE layers through here sequence by sequence — every sequence selects its own experts.
+// ------------------------------------------------------------------------------------------------
+int ffn_forward(lgh_ctx* c, LayerW& Lw, const FfnView& v, const float* next_nw, bool next_mfma) {
+  const lgh_model_desc& d = c->d;
+  const uint32_t H = d.hidden_size;
+  int rc;
+  // ---- FFN
+  if (!Lw.moe()) {
+    if (fused_type(Lw.gate.type) && Lw.gate.type == Lw.up.type) {  // FeedForward::forward (layers.rs:908-929)
+      SegSpec sp;
+      sp.npass = 2;
+      sp.W[0] = &Lw.gate; sp.W[1] = &Lw.up;
+      sp.x[0] = sp.x[1] = v.hidden;
+      sp.epi = EPI_SWIGLU;
+      sp.out = v.act;
+      sp.xq_next = mfma_type(Lw.down.type) ? 1 : 0;
+      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
+    } else {
+      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.gate, v.hidden, v.act, Lw.ffn_norm, nullptr, nullptr))) return rc;
+      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.up, v.hidden, v.act2, Lw.ffn_norm, nullptr, nullptr))) return rc;
+      if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return silu_mul_launch(v.act, v.act2, v.act, Lw.gate.n, c->stream); }))) return rc;
+      xq_stale(c, v.act);
+    }
+    return linear_any(c, LGH_K_DOWN, Lw.down, v.act, v.hidden, nullptr, v.hidden, nullptr, next_mfma ? 2 : 0, next_nw);
+  }
+  // ---- MoE (moe.rs:321-413): router + top-k on device, experts selected by device-side index
+  const uint32_t topk = d.num_experts_per_token;
+  if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)d.num_experts * H * 4, [&] {
+         return moe_router_launch(v.hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, d.num_experts, topk, v.moe_sel, v.moe_w, c->stream);
+       })))
+    return rc;
+  if (!fused_type(Lw.gate_exps.type) || Lw.gate_exps.type != Lw.up_exps.type || !fused_type(Lw.down_exps.type) || topk > 8)
+    return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 8");
+  // The selected experts run two at a time (a launch carries up to four passes: gate and up of two experts).  Every group
+  // reads the SAME normalised h, so the running sum lives in a scratch vector until the last group writes the residual
+  // stream: tmp = (w0 e0 + w1 e1) + h; tmp = (w2 e2 + w3 e3) + tmp; ...; h = (...) + tmp   (moe.rs:363-368 adds the weighted
+  // expert outputs in selection order and then the residual; same terms, grouped by two).
+  for (uint32_t g0 = 0; g0 < topk; g0 += 2) {
+    const uint32_t ng = std::min(2u, topk - g0);
+    const bool first_g = g0 == 0, last_g = g0 + ng >= topk;
+    {
+      SegSpec sp;
+      sp.npass = (int)(2 * ng);
+      for (uint32_t s = 0; s < ng; s++) {
+        sp.W[2 * s] = &Lw.gate_exps; sp.W[2 * s + 1] = &Lw.up_exps;
+        sp.x[2 * s] = sp.x[2 * s + 1] = v.hidden;
+        sp.sel[2 * s] = sp.sel[2 * s + 1] = v.moe_sel + g0 + s;
+      }
+      sp.epi = EPI_MOE_SWIGLU;
+      sp.out = v.act; sp.out2 = v.act2;
+      sp.xq_next = mfma_type(Lw.down_exps.type) ? 1 : 0;
+      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
+    }
+    {
+      SegSpec sp;
+      sp.npass = (int)ng;
+      for (uint32_t s = 0; s < ng; s++) {
+        sp.W[s] = &Lw.down_exps;
+        sp.x[s] = s == 0 ? v.act : v.act2;
+        sp.sel[s] = v.moe_sel + g0 + s;
+      }
+      sp.epi = EPI_MOE_DOWN;
+      sp.out = last_g ? v.hidden : v.xnorm;
+      sp.resid = first_g ? v.hidden : v.xnorm;
+      sp.moe_w = v.moe_w + g0;
+      sp.xq_next = last_g && next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
+      if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
+    }
+  }
+  return LGH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // one transformer layer (TransformerLayer::forward serial-residual branch, layers.rs:1187-1244)
 // ------------------------------------------------------------------------------------------------
@@ -525,70 +610,7 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
     // head of a token, on an idle stream, the same bracket reads differently from run to run)
     if ((rc = run_k(c, -1, -1, 0, [&] { return hipSuccess; }))) return rc;
   }
-  // ---- FFN
-  if (!Lw.moe()) {
-    if (fused_type(Lw.gate.type) && Lw.gate.type == Lw.up.type) {  // FeedForward::forward (layers.rs:908-929)
-      SegSpec sp;
-      sp.npass = 2;
-      sp.W[0] = &Lw.gate; sp.W[1] = &Lw.up;
-      sp.x[0] = sp.x[1] = c->hidden;
-      sp.epi = EPI_SWIGLU;
-      sp.out = c->act;
-      sp.xq_next = mfma_type(Lw.down.type) ? 1 : 0;
-      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
-    } else {
-      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.gate, c->hidden, c->act, Lw.ffn_norm, nullptr, nullptr))) return rc;
-      if ((rc = linear_any(c, LGH_K_GATEUP, Lw.up, c->hidden, c->act2, Lw.ffn_norm, nullptr, nullptr))) return rc;
-      if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return silu_mul_launch(c->act, c->act2, c->act, Lw.gate.n, c->stream); }))) return rc;
-      xq_stale(c, c->act);
-    }
-    return linear_any(c, LGH_K_DOWN, Lw.down, c->act, c->hidden, nullptr, c->hidden, nullptr, next_mfma ? 2 : 0, next_nw);
-  }
-  // ---- MoE (moe.rs:321-413): router + top-k on device, experts selected by device-side index
-  const uint32_t topk = d.num_experts_per_token;
-  if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)d.num_experts * H * 4, [&] {
-         return moe_router_launch(c->hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, d.num_experts, topk, c->moe_sel, c->moe_w, c->stream);
-       })))
-    return rc;
-  if (!fused_type(Lw.gate_exps.type) || Lw.gate_exps.type != Lw.up_exps.type || !fused_type(Lw.down_exps.type) || topk > 8)
-    return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 8");
-  // The selected experts run two at a time (a launch carries up to four passes: gate and up of two experts).  Every group
-  // reads the SAME normalised h, so the running sum lives in a scratch vector until the last group writes the residual
-  // stream: tmp = (w0 e0 + w1 e1) + h; tmp = (w2 e2 + w3 e3) + tmp; ...; h = (...) + tmp   (moe.rs:363-368 adds the weighted
-  // expert outputs in selection order and then the residual; same terms, grouped by two).
-  for (uint32_t g0 = 0; g0 < topk; g0 += 2) {
-    const uint32_t ng = std::min(2u, topk - g0);
-    const bool first_g = g0 == 0, last_g = g0 + ng >= topk;
-    {
-      SegSpec sp;
-      sp.npass = (int)(2 * ng);
-      for (uint32_t s = 0; s < ng; s++) {
-        sp.W[2 * s] = &Lw.gate_exps; sp.W[2 * s + 1] = &Lw.up_exps;
-        sp.x[2 * s] = sp.x[2 * s + 1] = c->hidden;
-        sp.sel[2 * s] = sp.sel[2 * s + 1] = c->moe_sel + g0 + s;
-      }
-      sp.epi = EPI_MOE_SWIGLU;
-      sp.out = c->act; sp.out2 = c->act2;
-      sp.xq_next = mfma_type(Lw.down_exps.type) ? 1 : 0;
-      if ((rc = launch_mv(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H))) return rc;
-    }
-    {
-      SegSpec sp;
-      sp.npass = (int)ng;
-      for (uint32_t s = 0; s < ng; s++) {
-        sp.W[s] = &Lw.down_exps;
-        sp.x[s] = s == 0 ? c->act : c->act2;
-        sp.sel[s] = c->moe_sel + g0 + s;
-      }
-      sp.epi = EPI_MOE_DOWN;
-      sp.out = last_g ? c->hidden : c->xnorm;
-      sp.resid = first_g ? c->hidden : c->xnorm;
-      sp.moe_w = c->moe_w + g0;
-      sp.xq_next = last_g && next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
-      if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;
-    }
-  }
-  return LGH_OK;
+  return ffn_forward(c, Lw, FfnView{c->hidden, c->act, c->act2, c->xnorm, c->moe_sel, c->moe_w}, next_nw, next_mfma);
 }
 
 // Everything one token needs, in stream order.  Used eagerly and under graph capture.
@@ -1183,6 +1205,10 @@ void lgh_destroy(lgh_ctx* c) {
       if (c->graph[m][v]) (void)hipGraphExecDestroy(c->graph[m][v]);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (void* p : c->allocs) (void)hipFree(p);
+  for (auto& gg : c->batch.graph)
+    for (auto& ge : gg)
+      if (ge) (void)hipGraphExecDestroy(ge);
+  if (c->batch.h_ctl) (void)hipHostFree(c->batch.h_ctl);
   if (c->pf.tok_pinned) (void)hipHostFree(c->pf.tok_pinned);
   if (c->pf.tok_copied) (void)hipEventDestroy(c->pf.tok_copied);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1259,6 +1285,40 @@ int lgh_prefill_batch(lgh_ctx* c, const uint32_t* tokens, size_t n) {
     if ((rc = lgh_prefill_token(c, tokens[i]))) return rc;
   HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   return LGH_OK;
+}
+
+// The prompt of one slot of the multi-sequence engine (engine_batch.hip): the batched prompt path with the slot's caches and
+// position in the context's place (same kernels, so the slot's K / V rows are the ones lgh_prefill_batch would write).
+int lgh_batch_prefill(lgh_ctx* c, uint32_t slot, const uint32_t* tokens, size_t n) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  BatchScratch& Bs = c->batch;
+  if (!Bs.ready || slot >= Bs.max_batch) return fail(c, LGH_INVALID_ARGUMENT, "no such slot (lgh_batch_create first)");
+  if (n && !tokens) return fail(c, LGH_INVALID_ARGUMENT, "tokens is NULL");
+  if (Bs.pos[slot] + n > c->d.max_seq_len) return fail(c, LGH_INVALID_ARGUMENT, "prompt exceeds max_seq_len");
+  for (size_t i = 0; i < n; i++)
+    if (tokens[i] >= c->d.vocab_size) return fail(c, LGH_INVALID_ARGUMENT, "token id exceeds vocab size");
+  if (n == 0) return LGH_OK;
+  if (!pf_eligible(c)) {   // no batched prompt path for this model: token by token through the multi-sequence step
+    for (size_t i = 0; i < n; i++)
+      if ((rc = lgh_forward_multi(c, &slot, tokens + i, 1, nullptr, nullptr))) return rc;
+    return LGH_OK;
+  }
+  const size_t keep = c->pos;
+  std::vector<std::pair<float*, float*>> saved;
+  for (uint32_t i = c->l0; i < c->l1; i++) {
+    saved.emplace_back(c->layers[i].kcache, c->layers[i].vcache);
+    c->layers[i].kcache = Bs.kcache[i] + (size_t)slot * Bs.cache_stride;
+    c->layers[i].vcache = Bs.vcache[i] + (size_t)slot * Bs.cache_stride;
+  }
+  c->pos = Bs.pos[slot];
+  for (size_t i = 0; i < n && !rc; i += kPfTokens) rc = prefill_block(c, tokens + i, (uint32_t)std::min<size_t>(kPfTokens, n - i));
+  if (!rc) Bs.pos[slot] = c->pos;
+  c->pos = keep;
+  for (uint32_t i = c->l0; i < c->l1; i++) { c->layers[i].kcache = saved[i - c->l0].first; c->layers[i].vcache = saved[i - c->l0].second; }
+  if (hipMemsetD32Async((hipDeviceptr_t)(c->state + ST_NEXT), (int)keep, 1, c->stream) != hipSuccess && !rc) rc = fail(c, LGH_OPERATION_FAILED, "state reset");
+  if (hipStreamSynchronize(c->stream) != hipSuccess && !rc) rc = fail(c, LGH_OPERATION_FAILED, "hipStreamSynchronize");
+  return rc;
 }
 
 void lgh_reset(lgh_ctx* c) {
@@ -1399,6 +1459,9 @@ int lgh_set_stream(lgh_ctx* c, void* s) {
     for (int m = 0; m < MODE_COUNT; m++)
       for (int v = 0; v < 2; v++)
         if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
+    for (auto& gg : c->batch.graph)
+      for (auto& ge : gg)
+        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
   }
   c->stream = ns;
   return LGH_OK;

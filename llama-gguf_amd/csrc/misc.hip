@@ -229,6 +229,41 @@ hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* 
   return hipGetLastError();
 }
 
+// multi-sequence decode: blockIdx.y = sequence s; logits v + s * n -> next[s] (last maximal index, as argmax_stage1/2)
+__global__ void __launch_bounds__(256) argmax_multi_stage1(const float* __restrict__ v, uint32_t n, float* pv, int* pi) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const uint32_t sq = blockIdx.y;
+  v += (size_t)sq * n;
+  float bv = -INFINITY;
+  int bi = -1;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) amax_merge(bv, bi, v[i], (int)i);
+  amax_block_reduce(bv, bi, sv, si);
+  if (threadIdx.x == 0) { pv[sq * kArgmaxParts + blockIdx.x] = bv; pi[sq * kArgmaxParts + blockIdx.x] = bi; }
+}
+
+__global__ void __launch_bounds__(64) argmax_multi_stage2(const float* pv, const int* pi, int nparts, int* next) {
+  const uint32_t sq = blockIdx.x;
+  float bv = -INFINITY;
+  int bi = -1;
+  for (int i = threadIdx.x; i < nparts; i += 64) amax_merge(bv, bi, pv[sq * kArgmaxParts + i], pi[sq * kArgmaxParts + i]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    float ov = __shfl_xor(bv, off, 64);
+    int oi = __shfl_xor(bi, off, 64);
+    amax_merge(bv, bi, ov, oi);
+  }
+  if (threadIdx.x == 0) next[sq] = bi < 0 ? 0 : bi;
+}
+
+// part_val / part_idx: n_seq * 64 words each
+hipError_t argmax_multi_launch(const float* logits, uint32_t n, uint32_t n_seq, float* part_val, int* part_idx, int* next, hipStream_t st) {
+  if (n_seq == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(argmax_multi_stage1, dim3(kArgmaxParts, n_seq), dim3(256), 0, st, logits, n, part_val, part_idx);
+  hipLaunchKernelGGL(argmax_multi_stage2, dim3(n_seq), dim3(64), 0, st, part_val, part_idx, kArgmaxParts, next);
+  return hipGetLastError();
+}
+
 // K/V rows of the current token into the caches (layers.rs:577-600; CUDA twin update_kv_cache,
 // kernels.rs:800-817) — only used when RoPE + cache write are not fused into the QKV launch.
 __global__ void __launch_bounds__(256) kv_store_kernel(const float* __restrict__ k, const float* __restrict__ v, float* kcache,

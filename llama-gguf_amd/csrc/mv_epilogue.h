@@ -43,11 +43,15 @@ __device__ __forceinline__ void mv_epilogue_prefetch_rope(int epi, uint32_t pos,
   }
 }
 
+// The vectors an epilogue writes and reads: the segment's own (single-sequence launches) or one sequence's slice of them
+// (matvec_batch.hip: every sequence has its own output, residual, XQ image, position and KV cache slot).
+struct MvEpiView { float* out; const float* resid; uint8_t* xq_out; float* xq_ssq; const int* pos; };
+
 // Per-row epilogue, one thread per row (or per row pair for RoPE)
 // `nslots` = partial sums per (pass, row) in `red`, laid out red[(p * nslots + slot) * rows_per_wg + row]
-__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red,
-                                            const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false},
-                                            uint32_t tid = threadIdx.x) {
+__device__ __forceinline__ void mv_epilogue_view(const MvLaunch& L, const MvSeg& S, const MvEpiView V, uint32_t wg, const float* red,
+                                                 const float* ssq, uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false},
+                                                 uint32_t tid = threadIdx.x) {
   const uint32_t t = tid;
   const uint32_t rbase = wg * S.rows_per_wg;
   float inv = 1.0f;
@@ -66,16 +70,16 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     if (rl >= S.rows_per_wg || row >= S.n_rows) return;
     float x0 = rowval(0, rl), x1 = rowval(0, rl + 1);
     if (S.bias) { x0 += S.bias[row]; x1 += S.bias[row + 1]; }
-    const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim, half = d / 2;
+    const uint32_t pos = (uint32_t)*V.pos, d = S.head_dim, half = d / 2;
     const uint32_t head = row / d, i = (row % d) / 2;
     const float c = pre.valid ? pre.a : L.rope_cs[((size_t)pos * half + i) * 2];
     const float s = pre.valid ? pre.b : L.rope_cs[((size_t)pos * half + i) * 2 + 1];
     float y0 = x0 * c - x1 * s, y1 = x0 * s + x1 * c;  // ops.rs:1326-1331
     if (S.epi == EPI_ROPE_Q) {
-      S.out[row] = y0;
-      S.out[row + 1] = y1;
+      V.out[row] = y0;
+      V.out[row + 1] = y1;
     } else {
-      float* dst = S.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
+      float* dst = V.out + ((size_t)head * S.max_seq + pos) * d + (row % d);
       dst[0] = y0;
       dst[1] = y1;
     }
@@ -89,27 +93,27 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   float outv = 0.0f;        // the value written to out[row] by the epilogues that can also leave an XQ image
   bool has_out = false;
   switch (S.epi) {
-    case EPI_STORE: outv = v0; S.out[row] = outv; has_out = true; break;
-    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : S.resid[row]); S.out[row] = outv; has_out = true; break;
+    case EPI_STORE: outv = v0; V.out[row] = outv; has_out = true; break;
+    case EPI_RESID: outv = v0 + (pre.valid ? pre.a : V.resid[row]); V.out[row] = outv; has_out = true; break;
     case EPI_SWIGLU: {
       float up = rowval(1, t);
       outv = silu_f(v0) * up;
-      S.out[row] = outv;
+      V.out[row] = outv;
       has_out = true;
       break;
     }
     case EPI_V_CACHE: {
-      const uint32_t pos = (uint32_t)*L.pos, d = S.head_dim;
-      S.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
+      const uint32_t pos = (uint32_t)*V.pos, d = S.head_dim;
+      V.out[((size_t)(row / d) * S.max_seq + pos) * d + (row % d)] = v0;
       break;
     }
     case EPI_MOE_SWIGLU: {
       for (int e = 0; 2 * e + 1 < S.npass; e++) {
         float g = rowval(2 * e, t), up = rowval(2 * e + 1, t);
-        float* o = e == 0 ? S.out : S.out2;
+        float* o = e == 0 ? V.out : S.out2;
         const float a = silu_f(g) * up;
         o[row] = a;
-        uint8_t* xo = e == 0 ? S.xq_out : S.xq_out2;   // each expert's activation feeds its own down projection
+        uint8_t* xo = e == 0 ? V.xq_out : S.xq_out2;   // each expert's activation feeds its own down projection
         if (xo) xq_store_chunk(xo, row >> 4, a, nullptr, 0.0f, tid);
       }
       break;
@@ -117,8 +121,8 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
     case EPI_MOE_DOWN: {
       float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
       for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
-      outv = acc + (pre.valid ? pre.a : S.resid[row]);
-      S.out[row] = outv;
+      outv = acc + (pre.valid ? pre.a : V.resid[row]);
+      V.out[row] = outv;
       has_out = true;
       break;
     }
@@ -127,12 +131,17 @@ __device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, u
   // ---- XQ image of the output for an int8-MFMA consumer (xq.h).  n_rows is a multiple of 16 here (host-checked), so the
   // 16 threads of a chunk are all live; with a norm in front of the consumer the record holds out * norm_weight and each
   // chunk leaves its sum of out^2.
-  uint8_t* xq = S.xq_out;
+  uint8_t* xq = V.xq_out;
   if (xq && has_out) {
     const float* nw = S.xq_nw;
     const float w = !nw ? 1.0f : (pre.valid && (S.epi == EPI_RESID || S.epi == EPI_MOE_DOWN)) ? pre.b : nw[row];
-    xq_store_chunk(xq, row >> 4, outv * w, S.xq_ssq, outv, tid);
+    xq_store_chunk(xq, row >> 4, outv * w, V.xq_ssq, outv, tid);
   }
+}
+
+__device__ __forceinline__ void mv_epilogue(const MvLaunch& L, const MvSeg& S, uint32_t wg, const float* red, const float* ssq,
+                                            uint32_t nslots, const MvEpiPre pre = MvEpiPre{0.0f, 0.0f, false}, uint32_t tid = threadIdx.x) {
+  mv_epilogue_view(L, S, MvEpiView{S.out, S.resid, S.xq_out, S.xq_ssq, L.pos}, wg, red, ssq, nslots, pre, tid);
 }
 
 }  // namespace lgh

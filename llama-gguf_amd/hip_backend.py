@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "lgh_pipeline_create", "lgh_pipeline_upload_tensor", "lgh_pipeline_finalize", "lgh_pipeline_destroy", "lgh_pipeline_forward",
     "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_stages",
     "lgh_pipeline_last_error",
+    "lgh_batch_create", "lgh_batch_reset", "lgh_batch_position", "lgh_batch_prefill", "lgh_forward_multi", "lgh_decode_greedy_multi",
 )
 
 K_NAMES = ("embed", "qkv", "attn", "attn_combine", "wo", "gate_up", "down", "router", "output", "argmax", "misc", "token")
@@ -156,6 +157,9 @@ def load_library() -> C.CDLL:
         "lgh_pipeline_forward": (C.c_int, [vp, u32, vp]), "lgh_pipeline_prefill_token": (C.c_int, [vp, u32]),
         "lgh_pipeline_decode_greedy": (C.c_int, [vp, u32, sz, vp]), "lgh_pipeline_reset": (None, [vp]),
         "lgh_pipeline_position": (sz, [vp]), "lgh_pipeline_stages": (C.c_int, [vp]), "lgh_pipeline_last_error": (C.c_char_p, [vp]),
+        "lgh_batch_create": (C.c_int, [vp, u32]), "lgh_batch_reset": (C.c_int, [vp, u32]), "lgh_batch_position": (sz, [vp, u32]),
+        "lgh_batch_prefill": (C.c_int, [vp, u32, vp, sz]), "lgh_forward_multi": (C.c_int, [vp, vp, vp, u32, vp, vp]),
+        "lgh_decode_greedy_multi": (C.c_int, [vp, vp, vp, u32, sz, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -283,6 +287,42 @@ class HipGpuInference:
     def decode_greedy(self, first_token: int, n_steps: int) -> np.ndarray:
         out = np.zeros(n_steps, dtype=np.uint32)
         self._call(load_library().lgh_decode_greedy(self._h, first_token, n_steps, out.ctypes.data))
+        return out
+
+    # -- multi-sequence decode: the device side of BatchedEngine (src/engine_batched.rs; include/llama_gguf_hip.h lgh_batch_*)
+    def batch_create(self, max_batch: int) -> None:
+        """`max_batch` slots (BatchedEngineConfig::max_batch_size), each one sequence's KV caches + position."""
+        self._call(load_library().lgh_batch_create(self._h, max_batch))
+
+    def batch_reset(self, slot: int) -> None:          # create_active_sequence: a fresh context for the slot
+        self._call(load_library().lgh_batch_reset(self._h, slot))
+
+    def batch_position(self, slot: int) -> int:
+        return load_library().lgh_batch_position(self._h, slot)
+
+    def batch_prefill(self, slot: int, tokens: Sequence[int]) -> None:
+        toks = np.ascontiguousarray(tokens, dtype=np.uint32)
+        self._call(load_library().lgh_batch_prefill(self._h, slot, toks.ctypes.data, toks.size))
+
+    def forward_multi(self, slots: Sequence[int], tokens: Sequence[int], want_logits: bool = True, greedy: bool = False):
+        """One iteration of the batched loop (engine_batched.rs:236-290): tokens[i] to slot slots[i], every weight read once.
+        Returns (logits [n_seq, vocab] or None, next tokens [n_seq] or None)."""
+        sl = np.ascontiguousarray(slots, dtype=np.uint32)
+        tk = np.ascontiguousarray(tokens, dtype=np.uint32)
+        assert sl.size == tk.size
+        logits = np.empty((sl.size, self.vocab_size), dtype=np.float32) if want_logits else None
+        nxt = np.zeros(sl.size, dtype=np.uint32) if greedy else None
+        self._call(load_library().lgh_forward_multi(self._h, sl.ctypes.data, tk.ctypes.data, sl.size,
+                                                    logits.ctypes.data if logits is not None else None,
+                                                    nxt.ctypes.data if nxt is not None else None))
+        return logits, nxt
+
+    def decode_greedy_multi(self, slots: Sequence[int], first_tokens: Sequence[int], n_steps: int) -> np.ndarray:
+        """n_steps greedy iterations, tokens fed back on the device; returns [n_steps, n_seq]."""
+        sl = np.ascontiguousarray(slots, dtype=np.uint32)
+        tk = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        out = np.zeros((n_steps, sl.size), dtype=np.uint32)
+        self._call(load_library().lgh_decode_greedy_multi(self._h, sl.ctypes.data, tk.ctypes.data, sl.size, n_steps, out.ctypes.data))
         return out
 
     # -- pipeline stage
