@@ -92,26 +92,35 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb_kernel(uint32_t wbpack, uin
     mvq_issue_tile<MASK>(fmt, tile_ptr(p1, b), lane, dst[1]);
   };
   float acc[NB][2];
-  auto process = [&](uint32_t g, uint32_t b, const RawT16 (&w)[2]) {
+  // The sequences' XQ operands come from L2 (~0.7 us away): a ring of kXd operand sets in registers; sequence s + kXd of the step
+  // is requested when sequence s has been used, and the first kXd sequences of the NEXT step at the end of a step — i.e. before
+  // that step requests its weight prefetch (a wave's loads return in order: a load issued behind the prefetch waits for HBM).
+  constexpr int kXd = NB >= 8 && !(NB == 16 && !kSingle) ? 3 : 2;   // (the mixed-format instantiations have no registers to spare at 16 sequences)
+  XqOps xr[kXd];
+  auto x_issue = [&](uint32_t b, int s, XqOps& o) { xq_load_ops(xg + (size_t)s * B.xq_stride + (size_t)b * kXqRecord, lane, o); };
+  auto x_prime = [&](uint32_t b) {
+#pragma unroll
+    for (int s = 0; s < kXd; s++)
+      if ((uint32_t)s < n_seq) x_issue(b, s, xr[s]);
+  };
+  auto process = [&](uint32_t g, uint32_t b, const RawT16 (&w)[2], bool more, uint32_t b_next) {
     const bool two = 2 * g + 1 < npairs;
     if (b == 0) {
 #pragma unroll
       for (int s = 0; s < NB; s++) acc[s][0] = acc[s][1] = 0.0f;
     }
-    XqOps cur, nxt;
-    xq_load_ops(xg + (size_t)b * kXqRecord, lane, cur);   // (requested before the tiles below are first touched)
     TileOps t0, t1;
     mvq_unpack_tile<MASK>(fmt, w[0], lane, t0);
     mvq_unpack_tile<MASK>(fmt, w[1], lane, t1);
 #pragma unroll
     for (int s = 0; s < NB; s++) {
       if ((uint32_t)s < n_seq) {
-        if ((uint32_t)s + 1 < n_seq) xq_load_ops(xg + (size_t)(s + 1) * B.xq_stride + (size_t)b * kXqRecord, lane, nxt);
-        mvq_mac_tile<MASK>(fmt, t0, cur, acc[s][0]);
-        if (two) mvq_mac_tile<MASK>(fmt, t1, cur, acc[s][1]);
-        cur = nxt;
+        mvq_mac_tile<MASK>(fmt, t0, xr[s % kXd], acc[s][0]);
+        if (two) mvq_mac_tile<MASK>(fmt, t1, xr[s % kXd], acc[s][1]);
+        if ((uint32_t)(s + kXd) < n_seq) x_issue(b, s + kXd, xr[s % kXd]);
       }
     }
+    if (more) x_prime(b_next);   // the next step's first sequences, ahead of its weight prefetch
     if (b + 1 == nblk_w) {   // last block of the group's pairs: the four lane groups -> one partial sum per row and sequence
 #pragma unroll
       for (int s = 0; s < NB; s++) {
@@ -134,18 +143,19 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb_kernel(uint32_t wbpack, uin
     RawT16 wa[2], wb[2];
     uint32_t g = 0, b = 0;                                  // the step being processed
     auto next = [&](uint32_t& gg, uint32_t& bb) { if (++bb == nblk_w) { bb = 0; ++gg; } };
+    x_prime(0);
     issue_step(0, 0, wa);
     for (uint32_t st = 0; st < nsteps; st += 2) {
       uint32_t g1 = g, b1 = b;
       next(g1, b1);
       const bool has1 = st + 1 < nsteps;
       if (has1) issue_step(g1, b1, wb); else issue_step(g, b, wb);
-      process(g, b, wa);
+      process(g, b, wa, has1, b1);
       uint32_t g2 = g1, b2 = b1;
       next(g2, b2);
       const bool has2 = st + 2 < nsteps;
       if (has2) issue_step(g2, b2, wa); else issue_step(g, b, wa);
-      if (has1) process(g1, b1, wb);
+      if (has1) process(g1, b1, wb, has2, b2);
       g = g2; b = b2;
     }
   }
