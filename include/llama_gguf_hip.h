@@ -82,7 +82,11 @@ typedef struct lgh_model_desc {
   uint32_t layer_begin;
   uint32_t layer_end;
   uint32_t flags;                    /* LGH_FLAG_* */
-  uint32_t kv_cache_type;            /* LGH_KV_*: the reference's KVCacheFormat (src/model/kv_quantized.rs:11-20; `--kv-cache-type`).
+  uint32_t kv_cache_type;            /* LGH_KV_*.  What the reference's `--kv-cache-type` can select is KVCacheType::{F32, TurboQuantMSE,
+                                        TurboQuantProd} (src/config.rs:808-817): LGH_KV_F32, LGH_KV_TQ2, LGH_KV_TQ3 here (Prod = QJL: not
+                                        implemented).  LGH_KV_INT8 / FP8_* are the formats of QuantizedKVCache (src/model/kv_quantized.rs:
+                                        11-20), which the reference exports (model/mod.rs:31, lib.rs:77) but which NO forward path and no
+                                        CLI flag of it reaches; they are offered for hosts that use that cache type directly.
                                         0 = f32, or int8 when LGH_FLAG_KV_INT8 is set (the field was added after the flag) */
 } lgh_model_desc;
 
@@ -91,6 +95,11 @@ enum {
   LGH_KV_INT8 = 1,                   /* int8 rows + one f32 scale per (kv head, position) */
   LGH_KV_FP8_E4M3 = 2,               /* one byte per element, no scales: the reference's quantize_fp8_e4m3 (mantissa truncated) */
   LGH_KV_FP8_E5M2 = 3,
+  /* KVCacheType::TurboQuantMSE { bits } (src/model/mod.rs:182-213): what `--kv-cache-type turboquant2 | tq2` / `turboquant3 | tq3`
+   * selects (src/config.rs:808-817) — randomized Hadamard rotation + Lloyd-Max scalar codes, src/model/turboquant/, cache and
+   * attention src/model/kv_turboquant.rs.  head_dim 64 or 128.  (The QJL variants tq2-qjl / tq3-qjl are not implemented.) */
+  LGH_KV_TQ2 = 4,
+  LGH_KV_TQ3 = 5,
 };
 
 enum {
@@ -226,6 +235,15 @@ int lgh_forward_argmax(lgh_ctx* ctx, uint32_t token_id, uint32_t* next_token);
 /* n_steps of greedy decode with the token fed back ON DEVICE (the loop of src/main.rs:1812-1822);
  * tokens_out[i] = arg-max after step i.  One host sync at the end. */
 int lgh_decode_greedy(lgh_ctx* ctx, uint32_t first_token, size_t n_steps, uint32_t* tokens_out);
+
+/* TurboQuant KV cache: the sign vectors of the rotations, [owned layer][kv head][k engine, v engine][head_dim] values of +1 / -1 =
+ * HadamardRotation::signs() (src/model/turboquant/rotation.rs:126-129) of TurboQuantKVCache's engines_k / engines_v
+ * (src/model/kv_turboquant.rs:44-71).  Call between lgh_create and lgh_finalize; without it the library uses a deterministic
+ * stand-in (valid rotations, but not the reference's StdRng stream). */
+int lgh_set_kv_rotation_signs(lgh_ctx* ctx, const float* signs, size_t n);
+/* one row through the TurboQuant compressor (TurboQuantEngine::compress without QJL, src/model/turboquant/quant.rs:71-103):
+ * x[dim] (dim 64 or 128), bits 2 or 3, signs[dim] -> codes[dim / 4 or dim / 8 * 3].  Bit-exact with the reference's arithmetic. */
+int lgh_op_tq_compress(int device, int bits, const float* x, size_t dim, const float* signs, uint8_t* codes);
 
 /* ---- multi-sequence decode: the device side of BatchedEngine (src/engine_batched.rs:23-194, 200-330, 355-400) ----
  * The reference keeps one InferenceContext (KV cache + position) per ActiveSequence (engine_batched.rs:84-100, 332-353) and every

@@ -1,0 +1,350 @@
+// attention_tq.hip — decode attention over the reference's TurboQuant KV cache (KVCacheType::TurboQuantMSE { bits: 2 | 3 }: what
+// `--kv-cache-type turboquant2 | turboquant3 (tq2 | tq3)` selects, src/config.rs:808-817, src/model/mod.rs:182-213).
+//
+// Replaces Backend::attention_turboquant (src/backend/mod.rs:240-264; its CPU body TurboQuantKVCache::attention_layer,
+// src/model/kv_turboquant.rs:127-201; the reference's CUDA twin `turboquant_attention_2bit`, src/backend/cuda/kernels.rs:
+// 1573-1687) and TurboQuantKVCache::write_kv (kv_turboquant.rs:88-122), as called from Attention::forward_turboquant
+// (src/model/layers.rs:843-852).
+//
+// Format (src/model/turboquant/): a head's K or V row x (head_dim f32) is stored as codes of  y = (1 / sqrt(d)) H D x  — D the
+// engine's random sign vector (rotation.rs:58-76; the signs are an INPUT of the library, lgh_set_kv_rotation_signs), H the
+// Walsh-Hadamard butterfly in the reference's order (rotation.rs:113-130) — every coordinate replaced by the index of its
+// Lloyd-Max cell for N(0, 1 / d) (codebook.rs:79-92: the number of boundaries it is >=), 2 bits (4 per byte) or 3 bits (8 per
+// 3 bytes, little-endian 24-bit groups) (codebook.rs:131-170).  CODES ARE BIT-EXACT with the reference's arithmetic: the
+// butterfly performs the same additions in the same order (tests: lgh_op_tq_compress vs the oracle).
+// Attention (kv_turboquant.rs:127-172): score_p = sum_i (H D q)_i c[K_p,i] — a strictly sequential f32 sum in the reference, and
+// here: one lane per cached position walks the 128 coordinates in order — times scale; softmax; out = sum_p w_p R^-1(c[V_p]).
+// The reference inverts the rotation per position; R^-1 is linear, so this kernel accumulates sum_p w_p c[V_p] in the rotated
+// space and the merge kernel inverts ONCE per head (rotation.rs:80-96) — same value up to f32 rounding; like the f32 attention
+// it does not apply the reference's `weight < 1e-8` skip (each skipped term is < 1e-8 of the output scale).
+//
+// Launch structure = the f32 / int8 caches': (kv head x split) workgroups leave (m, l, acc) partials, a merge kernel per query
+// head combines them — plus, here, the inverse rotation and the XQ image for the output projection.  The QKV launch leaves the
+// current token's rotated-by-RoPE K row and V row as f32 in a staging vector; every workgroup of a kv head compresses them
+// itself (identical bits everywhere), split 0 stores the codes at row `pos`, and the row takes part through its codes.
+#include <cmath>
+
+#include "device_utils.h"
+#include "xq.h"
+
+namespace lgh {
+
+struct TqTables { float cen[8]; float bnd[7]; float norm, inv_scale, inv_d; };   // host-computed (the oracle's own arithmetic)
+
+template <int BITS>
+__device__ __forceinline__ uint32_t tq_quantize(const TqTables& T, float v) {   // codebook.rs:79-92 (boundaries ascending)
+  uint32_t idx = 0;
+#pragma unroll
+  for (int i = 0; i < (1 << BITS) - 1; i++) idx += v >= T.bnd[i] ? 1u : 0u;
+  return idx;
+}
+template <int BITS>
+__device__ __forceinline__ float tq_centroid(const TqTables& T, uint32_t idx) {   // selects, no indexed register file
+  if (BITS == 2) {
+    const float lo = (idx & 1u) ? T.cen[1] : T.cen[0], hi = (idx & 1u) ? T.cen[3] : T.cen[2];
+    return (idx & 2u) ? hi : lo;
+  }
+  const float a = (idx & 1u) ? T.cen[1] : T.cen[0], b = (idx & 1u) ? T.cen[3] : T.cen[2];
+  const float c = (idx & 1u) ? T.cen[5] : T.cen[4], d = (idx & 1u) ? T.cen[7] : T.cen[6];
+  const float ab = (idx & 2u) ? b : a, cd = (idx & 2u) ? d : c;
+  return (idx & 4u) ? cd : ab;
+}
+template <int BITS>
+__device__ __forceinline__ uint32_t tq_index(const uint8_t* row, uint32_t i) {   // codebook.rs:173-252
+  if (BITS == 2) return (row[i >> 2] >> ((i & 3u) * 2)) & 3u;
+  const uint8_t* t = row + (i >> 3) * 3;
+  const uint32_t acc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16;
+  return (acc >> ((i & 7u) * 3)) & 7u;
+}
+template <int BITS>
+__host__ __device__ constexpr uint32_t tq_row_bytes(uint32_t d) { return BITS == 2 ? d / 4 : d / 8 * 3; }
+
+// In-place Walsh-Hadamard butterflies over `rows` vectors of D floats in LDS (rotation.rs:113-130): stage `half` combines (i, i +
+// half) exactly as the reference's loop does; all threads of the workgroup take part (barriers inside).
+template <int D>
+__device__ __forceinline__ void tq_fwht_rows(float* buf, uint32_t rows) {
+  for (uint32_t half = 1; half < (uint32_t)D; half <<= 1) {
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rows * (D / 2); j += blockDim.x) {
+      const uint32_t r = j / (D / 2), jj = j % (D / 2);
+      const uint32_t i = (jj / half) * 2 * half + (jj % half);
+      float* v = buf + r * D;
+      const float a = v[i], b = v[i + half];
+      v[i] = a + b;
+      v[i + half] = a - b;
+    }
+  }
+  __syncthreads();
+}
+
+// codes of the D floats at `y` (already rotated) -> row bytes, by the first D / 4 (2 bits) or D / 8 (3 bits) threads
+template <int D, int BITS>
+__device__ __forceinline__ void tq_pack_row(const TqTables& T, const float* y, uint8_t* out) {
+  if (BITS == 2) {
+    if (threadIdx.x < D / 4) {
+      uint32_t byte = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) byte |= tq_quantize<2>(T, y[threadIdx.x * 4 + i]) << (i * 2);
+      out[threadIdx.x] = (uint8_t)byte;
+    }
+  } else if (threadIdx.x < D / 8) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc |= tq_quantize<3>(T, y[threadIdx.x * 8 + i]) << (i * 3);
+    out[threadIdx.x * 3] = (uint8_t)(acc & 0xFF);
+    out[threadIdx.x * 3 + 1] = (uint8_t)((acc >> 8) & 0xFF);
+    out[threadIdx.x * 3 + 2] = (uint8_t)((acc >> 16) & 0xFF);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// split attention over the code caches.  grid = n_kv * n_splits, 256 threads.
+// signs: this layer's [kv head][k, v][D]; k_new / v_new: the current token's f32 rows [kv head][D]
+// dynamic LDS: (G + 2) * D floats (rotated queries, the current K row, the current V row) + 2 * row bytes (its codes, 16-aligned)
+//              + G * cap floats (scores of this split's positions) + 64 floats of reduction scratch
+// ------------------------------------------------------------------------------------------------
+template <int D, int G, int BITS>
+__global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __restrict__ q, uint8_t* __restrict__ kq, uint8_t* __restrict__ vq,
+                                                              const float* __restrict__ k_new, const float* __restrict__ v_new,
+                                                              const float* __restrict__ signs, const TqTables T, uint32_t max_seq, float scale,
+                                                              const int* pos_ptr, uint32_t n_splits, uint32_t cap,
+                                                              float* __restrict__ part_ml, float* __restrict__ part_acc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr uint32_t RB = tq_row_bytes<BITS>(D);
+  float* rot = reinterpret_cast<float*>(smem);                       // [G + 2][D]
+  uint8_t* newk = smem + (G + 2) * D * 4;                            // [RB] (padded to 64)
+  uint8_t* newv = newk + 64;
+  float* sc = reinterpret_cast<float*>(newv + 64);                   // [G][cap]
+  float* redm = sc + (size_t)G * cap;                                // [G][8]  per-wave maxima / sums
+  const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t pw;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
+  const uint32_t pos = pw, kv_len = pw + 1;
+  const float* sk = signs + (size_t)(kvh * 2) * D;
+  const float* sv = sk + D;
+  // ---- D x (sign flip), then H, then 1 / sqrt(d): the G query heads with the K engine's signs, the new K row, the new V row
+  for (uint32_t e = tid; e < (G + 2) * D; e += 256) {
+    const uint32_t r = e / D, i = e % D;
+    float v;
+    if (r < G) v = q[((size_t)kvh * G + r) * D + i] * sk[i];
+    else if (r == G) v = k_new[(size_t)kvh * D + i] * sk[i];
+    else v = v_new[(size_t)kvh * D + i] * sv[i];
+    rot[e] = v;
+  }
+  tq_fwht_rows<D>(rot, G + 2);
+  for (uint32_t e = tid; e < (G + 2) * D; e += 256) rot[e] *= T.norm;
+  __syncthreads();
+  tq_pack_row<D, BITS>(T, rot + G * D, newk);
+  tq_pack_row<D, BITS>(T, rot + (G + 1) * D, newv);
+  __syncthreads();
+  uint8_t* krow0 = kq + (size_t)kvh * max_seq * RB;
+  uint8_t* vrow0 = vq + (size_t)kvh * max_seq * RB;
+  if (sp == 0 && tid < RB) { krow0[(size_t)pos * RB + tid] = newk[tid]; vrow0[(size_t)pos * RB + tid] = newv[tid]; }
+  // ---- scores: position p = (it * 256 + tid) * n_splits + sp; one lane walks the D coordinates of its position in order
+  const uint32_t npos = kv_len > sp ? (kv_len - sp + n_splits - 1) / n_splits : 0;   // positions of this split
+  float mloc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) mloc[g] = -1e30f;
+  for (uint32_t j = tid; j < npos; j += 256) {
+    const uint32_t p = j * n_splits + sp;
+    uint32_t words[RB / 4];
+    const uint8_t* row = p == pos ? newk : krow0 + (size_t)p * RB;
+#pragma unroll
+    for (uint32_t w = 0; w < RB / 4; w++) words[w] = *reinterpret_cast<const uint32_t*>(row + 4 * w);
+    float s[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) s[g] = 0.0f;
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)D; i++) {
+      uint32_t idx;
+      if (BITS == 2) idx = (words[i >> 4] >> ((i & 15u) * 2)) & 3u;
+      else {
+        const uint32_t bit = (i >> 3) * 24 + (i & 7u) * 3;            // 24-bit groups, little-endian
+        const uint32_t w0 = words[bit >> 5], sh = bit & 31u;
+        idx = (sh <= 29 ? (w0 >> sh) : ((w0 >> sh) | (words[(bit >> 5) + 1] << (32 - sh)))) & 7u;
+      }
+      const float cv = tq_centroid<BITS>(T, idx);
+#pragma unroll
+      for (int g = 0; g < G; g++) s[g] += rot[g * D + i] * cv;        // sum += query[i] * centroid (codebook.rs:228-248)
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      s[g] *= scale;
+      sc[(size_t)g * cap + j] = s[g];
+      mloc[g] = fmaxf(mloc[g], s[g]);
+    }
+  }
+  // ---- the split's softmax state per head: m = max, l = sum exp(s - m)
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const float m = wave_max(mloc[g]);
+    if (lane == 0) redm[g * 8 + wave] = m;
+  }
+  __syncthreads();
+  float msplit[G], lloc[G];
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    msplit[g] = fmaxf(fmaxf(redm[g * 8], redm[g * 8 + 1]), fmaxf(redm[g * 8 + 2], redm[g * 8 + 3]));
+    lloc[g] = 0.0f;
+  }
+  for (uint32_t j = tid; j < npos; j += 256) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const float e = expf(sc[(size_t)g * cap + j] - msplit[g]);
+      sc[(size_t)g * cap + j] = e;
+      lloc[g] += e;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    const float l = wave_sum(lloc[g]);
+    if (lane == 0) redm[g * 8 + 4 + wave] = l;
+  }
+  __syncthreads();
+  // ---- sum_p w_p c[V_p] in the rotated space: thread <-> (head, coordinate), positions in ascending order
+  const size_t pbase = ((size_t)kvh * n_splits + sp) * G;
+  for (uint32_t e = tid; e < (uint32_t)(G * D); e += 256) {
+    const uint32_t g = e / D, i = e % D;
+    float acc = 0.0f;
+    for (uint32_t j = 0; j < npos; j++) {
+      const uint32_t p = j * n_splits + sp;
+      const uint8_t* row = p == pos ? newv : vrow0 + (size_t)p * RB;
+      acc += sc[(size_t)g * cap + j] * tq_centroid<BITS>(T, tq_index<BITS>(row, i));
+    }
+    part_acc[(pbase + g) * D + i] = acc;
+    if (i == 0) {
+      part_ml[(pbase + g) * 2] = msplit[g];
+      part_ml[(pbase + g) * 2 + 1] = (redm[g * 8 + 4] + redm[g * 8 + 5]) + (redm[g * 8 + 6] + redm[g * 8 + 7]);
+    }
+  }
+}
+
+// merge of the splits (as attn_combine_kernel) + the inverse rotation (rotation.rs:80-96): out = signs * (1 / d) * H (sqrt(d) * o)
+template <int D>
+__global__ void __launch_bounds__(D) attn_tq_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
+                                                            const float* __restrict__ signs, const TqTables T, uint32_t g_per_kv,
+                                                            uint32_t n_splits, float* __restrict__ out, uint8_t* __restrict__ xq_out) {
+  __shared__ float s_f[64];
+  __shared__ float s_linv;
+  __shared__ float buf[D];
+  const uint32_t h = blockIdx.x, kvh = h / g_per_kv, g = h % g_per_kv;
+  const size_t p0 = (size_t)kvh * n_splits * g_per_kv + g;
+  const uint32_t dim = threadIdx.x;
+  float pa[32];
+#pragma unroll
+  for (uint32_t s = 0; s < 32; s++) pa[s] = s < n_splits ? part_acc[(p0 + (size_t)s * g_per_kv) * D + dim] : 0.0f;
+  if (threadIdx.x < 64) {
+    const uint32_t s = threadIdx.x;
+    const bool ok = s < n_splits;
+    const float m = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2] : -1e30f;
+    const float l = ok ? part_ml[(p0 + (size_t)s * g_per_kv) * 2 + 1] : 0.0f;
+    const float mn = wave_max(m);
+    const float f = expf(m - mn);
+    const float lsum = wave_sum(l * f);
+    s_f[s] = f;
+    if (s == 0) s_linv = 1.0f / lsum;
+  }
+  __syncthreads();
+  float a = 0.0f;
+#pragma unroll
+  for (uint32_t s = 0; s < 32; s++) a += pa[s] * s_f[s];
+  buf[dim] = (a * s_linv) * T.inv_scale;                              // x * sqrt(d)
+  tq_fwht_rows<D>(buf, 1);
+  const float o = buf[dim] * T.inv_d * signs[(size_t)(kvh * 2 + 1) * D + dim];
+  out[(size_t)h * D + dim] = o;
+  if (xq_out) xq_store_chunk(xq_out, (h * D + dim) >> 4, o);
+}
+
+// one row through the compressor (the code path of attn_tq_partial_kernel's new-row handling, stand-alone): lgh_op_tq_compress
+template <int D, int BITS>
+__global__ void __launch_bounds__(256) tq_compress_kernel(const float* __restrict__ x, const float* __restrict__ signs, const TqTables T,
+                                                          uint8_t* __restrict__ out) {
+  __shared__ float rot[D];
+  __shared__ uint8_t code[64];
+  for (uint32_t i = threadIdx.x; i < D; i += 256) rot[i] = x[i] * signs[i];
+  tq_fwht_rows<D>(rot, 1);
+  for (uint32_t i = threadIdx.x; i < D; i += 256) rot[i] *= T.norm;
+  __syncthreads();
+  tq_pack_row<D, BITS>(T, rot, code);
+  __syncthreads();
+  if (threadIdx.x < tq_row_bytes<BITS>(D)) out[threadIdx.x] = code[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+static TqTables tq_tables(uint32_t d, int bits) {
+  // Codebook::new (codebook.rs:55-77) and the rotation's factors (rotation.rs:72, 84, 91) in host f32 arithmetic
+  static const float l2[4] = {-1.5102326f, -0.4528427f, 0.4528427f, 1.5102326f};
+  static const float l3[8] = {-2.1521645f, -1.3441838f, -0.7561303f, -0.2453404f, 0.2453404f, 0.7561303f, 1.3441838f, 2.1521645f};
+  static const float b2[3] = {-0.98153765f, 0.0f, 0.98153765f};
+  static const float b3[7] = {-1.74817415f, -1.05015705f, -0.50073535f, 0.0f, 0.50073535f, 1.05015705f, 1.74817415f};
+  TqTables T{};
+  const float inv_sqrt_d = 1.0f / std::sqrt((float)d);
+  for (int i = 0; i < (1 << bits); i++) T.cen[i] = (bits == 2 ? l2[i] : l3[i]) * inv_sqrt_d;
+  for (int i = 0; i < (1 << bits) - 1; i++) T.bnd[i] = (bits == 2 ? b2[i] : b3[i]) * inv_sqrt_d;
+  T.norm = 1.0f / std::sqrt((float)d);
+  T.inv_scale = std::sqrt((float)d);
+  T.inv_d = 1.0f / (float)d;
+  return T;
+}
+
+uint32_t tq_row_bytes_host(int bits, uint32_t d) { return bits == 2 ? d / 4 : d / 8 * 3; }
+// positions one split can hold scores for: max_seq spread over the splits
+uint32_t tq_split_cap(uint32_t max_seq, uint32_t n_splits) { return (max_seq + n_splits - 1) / n_splits; }
+
+template <int D, int G, int BITS>
+static hipError_t attn_tq_go(const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs, uint32_t n_kv,
+                             uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
+  static bool attr_set[64] = {};
+  const uint32_t cap = tq_split_cap(max_seq, n_splits);
+  const size_t lds = (size_t)(G + 2) * D * 4 + 128 + (size_t)G * cap * 4 + (size_t)G * 8 * 4 + 64;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS>), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS>), dim3(n_kv * n_splits), dim3(256), lds, st, q, kq, vq, k_new, v_new, signs,
+                     tq_tables(D, BITS), max_seq, scale, pos, n_splits, cap, part_ml, part_acc);
+  return hipGetLastError();
+}
+
+// bits 2 / 3; signs: this layer's [n_kv][2][head_dim]
+hipError_t attn_tq_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs,
+                          uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
+                          float* part_ml, float* part_acc, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || !pos || (bits != 2 && bits != 3) || n_splits == 0 || n_splits > 32) return hipErrorInvalidValue;
+  const uint32_t g = n_heads / n_kv;
+#define LGH_TQ_CASE(DD, GG)                                                                                                            \
+  if (head_dim == DD && g == GG)                                                                                                       \
+    return bits == 2 ? attn_tq_go<DD, GG, 2>(q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st) \
+                     : attn_tq_go<DD, GG, 3>(q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st);
+  LGH_TQ_CASE(128, 1) LGH_TQ_CASE(128, 2) LGH_TQ_CASE(128, 4) LGH_TQ_CASE(128, 8)
+  LGH_TQ_CASE(64, 1) LGH_TQ_CASE(64, 2) LGH_TQ_CASE(64, 4) LGH_TQ_CASE(64, 8)
+#undef LGH_TQ_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t attn_tq_combine_launch(int bits, const float* part_ml, const float* part_acc, const float* signs, uint32_t n_heads, uint32_t n_kv,
+                                  uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
+  if (n_kv == 0 || n_heads % n_kv || n_splits > 32 || (head_dim != 64 && head_dim != 128)) return hipErrorInvalidValue;
+  if (head_dim == 128)
+    hipLaunchKernelGGL(attn_tq_combine_kernel<128>, dim3(n_heads), dim3(128), 0, st, part_ml, part_acc, signs, tq_tables(128, bits), n_heads / n_kv,
+                       n_splits, out, xq_out);
+  else
+    hipLaunchKernelGGL(attn_tq_combine_kernel<64>, dim3(n_heads), dim3(64), 0, st, part_ml, part_acc, signs, tq_tables(64, bits), n_heads / n_kv,
+                       n_splits, out, xq_out);
+  return hipGetLastError();
+}
+
+// x[dim] -> codes[row bytes] with the given sign vector (dim 64 or 128)
+hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st) {
+  if ((bits != 2 && bits != 3) || (dim != 64 && dim != 128)) return hipErrorInvalidValue;
+  const TqTables T = tq_tables(dim, bits);
+  if (dim == 128 && bits == 2) hipLaunchKernelGGL((tq_compress_kernel<128, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out);
+  else if (dim == 128) hipLaunchKernelGGL((tq_compress_kernel<128, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out);
+  else if (bits == 2) hipLaunchKernelGGL((tq_compress_kernel<64, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out);
+  else hipLaunchKernelGGL((tq_compress_kernel<64, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out);
+  return hipGetLastError();
+}
+
+}  // namespace lgh

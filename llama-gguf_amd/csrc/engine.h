@@ -101,6 +101,8 @@ struct lgh_ctx {
   std::vector<lgh::XqBuf> xqs;
   lgh::PfScratch pf;
   lgh::BatchScratch batch;
+  float* tq_signs = nullptr;                   // TurboQuant KV cache: [owned layer][kv head][k, v][head_dim] rotation signs (device)
+  std::vector<float> tq_signs_host;
   float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 

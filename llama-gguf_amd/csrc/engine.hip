@@ -64,6 +64,7 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
 // otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
 // 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
 constexpr uint32_t kDirectAttnDefaultKv = 64;
+static inline bool kv_is_tq(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ3; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
@@ -555,7 +556,25 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
   const float scale = 1.0f / std::sqrt((float)d.head_dim);  // layers.rs:374
   const uint64_t kv_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) *
                             (d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4 : kv8 ? d.head_dim : d.head_dim * 4);
-  if (kv8) {
+  if (kv_is_tq(d.kv_cache_type)) {
+    // TurboQuantKVCache (kv_turboquant.rs): write_kv + attention_layer over the codes; the merge also inverts the V rotation
+    const int bits = d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3;
+    const float* signs = c->tq_signs + (size_t)(li - c->l0) * d.num_kv_heads * 2 * d.head_dim;
+    const uint64_t tq_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * tq_row_bytes_host(bits, d.head_dim);
+    if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, tq_bytes, [&] {
+           return attn_tq_launch(bits, c->q, (uint8_t*)Lw.k8, (uint8_t*)Lw.v8, k_new, v_new, signs, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
+                                 scale, c->state + ST_POS, c->n_splits, c->part_ml, c->part_acc, c->stream);
+         })))
+      return rc;
+    XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
+    if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
+           return attn_tq_combine_launch(bits, c->part_ml, c->part_acc, signs, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, c->attn_out,
+                                         qa ? qa->xq : nullptr, c->stream);
+         })))
+      return rc;
+    if (qa) { qa->fresh = true; qa->tag = nullptr; }
+    else xq_stale(c, c->attn_out);
+  } else if (kv8) {
     // int8 rows + scales (kv_quantized.rs); the launch also quantizes and stores the current token's rows
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, kv_bytes, [&] {
            return attn_q8_launch((int)d.kv_cache_type, c->q, Lw.k8, Lw.v8, Lw.kscale, Lw.vscale, k_new, v_new, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
@@ -917,6 +936,10 @@ int engine_shape_check(const lgh_model_desc& d, std::string& why) {
     why = "the int8 KV cache runs on the split attention kernels (head_dim 64 / 128; 1, 2, 4 or 8 query heads per kv head) of the default decode path";
     return LGH_UNSUPPORTED;
   }
+  if (kv_is_tq(d.kv_cache_type) && (d.head_dim != 64 && d.head_dim != 128)) {
+    why = "the TurboQuant KV cache rotates rows of 64 or 128 values (head_dim a power of two)";
+    return LGH_UNSUPPORTED;
+  }
   if (d.num_experts && (d.num_experts_per_token == 0 || d.num_experts_per_token > 8 || d.num_experts_per_token > d.num_experts || d.num_experts > 64)) {
     why = "MoE layers route top-1 .. top-8 over at most 64 experts; this model routes top-" +
           std::to_string(d.num_experts_per_token) + " over " + std::to_string(d.num_experts);
@@ -941,7 +964,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   lgh_model_desc d{};
   std::memcpy(&d, desc, desc->struct_size);
   d.struct_size = sizeof(lgh_model_desc);
-  if (d.kv_cache_type > LGH_KV_FP8_E5M2) return LGH_INVALID_ARGUMENT;
+  if (d.kv_cache_type > LGH_KV_TQ3) return LGH_INVALID_ARGUMENT;
   if (d.flags & LGH_FLAG_REMOVED_MASK) return LGH_UNSUPPORTED;   // the decode structures removed in round 3 (llama_gguf_hip.h)
   if (d.kv_cache_type == LGH_KV_F32 && (d.flags & LGH_FLAG_KV_INT8)) d.kv_cache_type = LGH_KV_INT8;
   // every byte-per-element cache shares the int8 cache's structure (staged f32 rows, the attention launch quantizes and stores
@@ -978,6 +1001,21 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   c->direct_attn_max_kv = dsel == 255 ? 0 : dsel ? dsel * 64 : kDirectAttnDefaultKv;
   if (d.flags & LGH_FLAG_KV_INT8) c->direct_attn_max_kv = 0;   // the byte caches have one attention structure: splits + combine
   *out = c;
+  return LGH_OK;
+}
+
+// The sign vectors of the TurboQuant rotations (HadamardRotation::signs(), src/model/turboquant/rotation.rs:126-129), before
+// lgh_finalize: [owned layer][kv head][k engine, v engine][head_dim] values of +1 / -1 — what the reference draws per engine from
+// its seeds (kv_turboquant.rs:44-71: base = layer * kv_heads + head; rotation seeds 4 base and 4 base + 2).
+int lgh_set_kv_rotation_signs(lgh_ctx* c, const float* signs, size_t n) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (c->finalized) return fail(c, LGH_INVALID_ARGUMENT, "the rotation signs must be given before lgh_finalize");
+  if (!kv_is_tq(c->d.kv_cache_type)) return fail(c, LGH_INVALID_ARGUMENT, "this context has no TurboQuant KV cache");
+  const size_t want = (size_t)(c->l1 - c->l0) * c->d.num_kv_heads * 2 * c->d.head_dim;
+  if (!signs || n != want) return fail(c, LGH_INVALID_ARGUMENT, "expected " + std::to_string(want) + " sign values");
+  for (size_t i = 0; i < n; i++)
+    if (signs[i] != 1.0f && signs[i] != -1.0f) return fail(c, LGH_INVALID_ARGUMENT, "sign values must be +1 or -1");
+  c->tq_signs_host.assign(signs, signs + n);
   return LGH_OK;
 }
 
@@ -1124,6 +1162,15 @@ int lgh_finalize(lgh_ctx* c) {
     if (d.flags & LGH_FLAG_KV_INT8) {
       // QuantizedKVCache::new with KVCacheFormat::Int8 (kv_quantized.rs:57-102): int8 rows + a scale per (kv head, position)
       const size_t n_rows = (size_t)d.num_kv_heads * d.max_seq_len;
+      if (kv_is_tq(d.kv_cache_type)) {   // TurboQuantKVCache::new (kv_turboquant.rs:36-86): packed codes, no scales, no norms
+        const size_t bytes = n_rows * tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim);
+        for (int8_t** p8 : {&L.k8, &L.v8}) {
+          if ((rc = dev_alloc(c, (void**)p8, bytes))) return rc;
+          HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*p8, 0, bytes, c->stream));
+        }
+        c->stats.kv_bytes += 2 * bytes;
+        continue;
+      }
       for (int8_t** p8 : {&L.k8, &L.v8}) {
         if ((rc = dev_alloc(c, (void**)p8, kv_elems))) return rc;
         HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*p8, 0, kv_elems, c->stream));
@@ -1170,6 +1217,23 @@ int lgh_finalize(lgh_ctx* c) {
     if ((rc = dev_alloc(c, b.p, b.n))) return rc;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*b.p, 0, b.n, c->stream));
     c->stats.scratch_bytes += b.n;
+  }
+  if (kv_is_tq(d.kv_cache_type)) {
+    // the rotations' sign vectors, [owned layer][kv head][k, v][head_dim]: given through lgh_set_kv_rotation_signs (the Rust host
+    // passes every engine's HadamardRotation::signs()), otherwise a deterministic stand-in — NOT the reference's StdRng stream
+    const size_t n = (size_t)(c->l1 - c->l0) * d.num_kv_heads * 2 * d.head_dim;
+    if (c->tq_signs_host.empty()) {
+      c->tq_signs_host.resize(n);
+      for (size_t i = 0; i < n; i++) {
+        const uint64_t engine = (uint64_t)c->l0 * d.num_kv_heads * 2 + i / d.head_dim;   // (layer * kv_heads + head) * 2 + {k, v}
+        uint64_t z = (engine * 0x9E3779B97F4A7C15ull) ^ ((i % d.head_dim) * 0xBF58476D1CE4E5B9ull);
+        z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+        c->tq_signs_host[i] = (z & 1) ? 1.0f : -1.0f;
+      }
+    }
+    if (c->tq_signs_host.size() != n) return fail(c, LGH_INVALID_ARGUMENT, "the rotation sign vector has the wrong length for this context");
+    if ((rc = dev_alloc(c, (void**)&c->tq_signs, n * 4))) return rc;
+    HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(c->tq_signs, c->tq_signs_host.data(), n * 4, hipMemcpyHostToDevice));
   }
   // XQ images of the vectors that feed quantized mat-vecs (allocated here, never during a graph capture)
   if (!xq_get(c, c->hidden, d.hidden_size) || !xq_get(c, c->attn_out, d.num_heads * d.head_dim) || !xq_get(c, c->act, (uint32_t)ffn) ||
@@ -1362,7 +1426,10 @@ int lgh_kv_shift_left(lgh_ctx* c, size_t amount) {
     };
     for (uint32_t li = c->l0; li < c->l1; li++) {
       LayerW& L = c->layers[li];
-      if (d.flags & LGH_FLAG_KV_INT8) {
+      if (kv_is_tq(d.kv_cache_type)) {   // TurboQuantKVCache::shift_left (kv_turboquant.rs:245-266): code rows
+        const size_t rb = tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim);
+        if ((rc = shift(L.k8, rb)) || (rc = shift(L.v8, rb))) return rc;
+      } else if (d.flags & LGH_FLAG_KV_INT8) {
         if ((rc = shift(L.k8, d.head_dim)) || (rc = shift(L.v8, d.head_dim))) return rc;
         if (d.kv_cache_type == LGH_KV_INT8 && ((rc = shift(L.kscale, 4)) || (rc = shift(L.vscale, 4)))) return rc;
       } else if ((rc = shift(L.kcache, row)) || (rc = shift(L.vcache, row))) {
@@ -1421,7 +1488,8 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
       if (L.moe()) b += (uint64_t)d.num_experts_per_token * (L.gate_exps.bytes + L.up_exps.bytes + L.down_exps.bytes) + (uint64_t)d.num_experts * d.hidden_size * 4;
       else b += L.gate.bytes + L.up.bytes + L.down.bytes;
       b += (uint64_t)2 * d.hidden_size * 4;                                       // norm weights
-      const uint64_t kv_row = d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4                                // int8 row + its scale
+      const uint64_t kv_row = kv_is_tq(d.kv_cache_type) ? tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim)
+                              : d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4                                // int8 row + its scale
                               : d.kv_cache_type != LGH_KV_F32 ? d.head_dim : (uint64_t)d.head_dim * 4;
       b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * kv_row;                  // KV read (kv_len = pos+1)
       b += (uint64_t)2 * d.num_kv_heads * kv_row;                                 // KV write

@@ -277,6 +277,25 @@ int lgh_op_kv_roundtrip(int device, uint32_t kv_cache_type, const float* row, si
   return t.down(back_out, dback, n);
 }
 
+int lgh_op_tq_compress(int device, int bits, const float* x, size_t dim, const float* signs, uint8_t* codes) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!x || !signs || !codes) return LGH_INVALID_ARGUMENT;
+  if ((bits != 2 && bits != 3) || (dim != 64 && dim != 128)) return LGH_UNSUPPORTED;
+  for (size_t i = 0; i < dim; i++)
+    if (signs[i] != 1.0f && signs[i] != -1.0f) return LGH_INVALID_ARGUMENT;
+  float *dx = t.up(x, dim), *ds = t.up(signs, dim);
+  const size_t rb = tq_row_bytes_host(bits, (uint32_t)dim);
+  uint8_t* dc = reinterpret_cast<uint8_t*>(t.up(nullptr, (rb + 3) / 4));
+  if (!dx || !ds || !dc) return LGH_ALLOCATION_FAILED;
+  if (tq_compress_launch(bits, dx, (uint32_t)dim, ds, dc, t.c->stream) != hipSuccess) return LGH_OPERATION_FAILED;
+  std::vector<float> tmp((rb + 3) / 4);
+  int rc = t.down(tmp.data(), reinterpret_cast<float*>(dc), (rb + 3) / 4);
+  if (rc) return rc;
+  std::memcpy(codes, tmp.data(), rb);
+  return LGH_OK;
+}
+
 int lgh_op_matmul(int device, const float* a, const float* b, float* out, size_t m, size_t k, size_t n) {
   Tmp t(device);
   if (t.rc) return t.rc;

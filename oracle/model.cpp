@@ -66,6 +66,10 @@ struct orc_model {
   std::vector<std::vector<float>> k_cache, v_cache;  // per layer [kv_heads][max_seq][head_dim]
   bool kv_int8 = false;                               // rows go through the reference's int8 KV format on their way into the cache
   int kv_fp8 = 0;                                     // ... or through one of its FP8 formats (1: E4M3, 2: E5M2)
+  // TurboQuantKVCache (src/model/kv_turboquant.rs): Attention::forward_turboquant (layers.rs:711-873) instead of the f32 cache
+  int kv_tq_bits = 0;                                 // 2 / 3: KVCacheType::TurboQuantMSE { bits } (model/mod.rs:182-213)
+  std::vector<float> tq_signs;                        // [layer][kv head][k, v][padded_dim]: HadamardRotation::signs() of every engine
+  std::vector<std::vector<uint8_t>> tq_k, tq_v;       // per layer [kv head][max_seq][packed bytes]
   std::vector<float> last_hidden;
   size_t position = 0;
   bool finalized = false;
@@ -130,9 +134,32 @@ int attention_forward(orc_model* m, size_t li, const float* x, size_t pos, float
   if (linear_forward(m, L.wk, x, k.data())) return 1;  // 439
   if (linear_forward(m, L.wv, x, v.data())) return 1;  // 440
   orc_rope(q.data(), k.data(), nh, nkv, 1, d, pos, c.rope_freq_base, c.rope_freq_scale, (int)c.use_neox_rope);  // 565-575
+  size_t ms = c.max_seq_len;
+  if (m->kv_tq_bits) {
+    // forward_turboquant (layers.rs:843-852): tq_cache.write_kv(layer, k, v) — every kv head's row compressed by that head's
+    // K / V engine (kv_turboquant.rs:88-122) — then backend.attention_turboquant = attention_layer (173-201): query head h reads
+    // kv head h / (heads per kv head)
+    const int bits = m->kv_tq_bits;
+    const size_t pd = orc_tq_padded_dim(d), pb = orc_tq_packed_bytes(bits, pd);
+    uint8_t* kq = m->tq_k[li].data();
+    uint8_t* vq = m->tq_v[li].data();
+    auto signs = [&](size_t h, int kv) { return m->tq_signs.data() + ((li * nkv + h) * 2 + (size_t)kv) * pd; };
+    for (size_t h = 0; h < nkv; h++) {
+      orc_tq_compress(k.data() + h * d, d, bits, signs(h, 0), kq + (h * ms + pos) * pb);
+      orc_tq_compress(v.data() + h * d, d, bits, signs(h, 1), vq + (h * ms + pos) * pb);
+    }
+    std::vector<float> attn_tq(nh * d);
+    const float scale_tq = 1.0f / std::sqrt((float)d);  // layers.rs:374
+    const size_t per = nh / nkv;
+    for (size_t h = 0; h < nh; h++) {
+      const size_t kvh = h / per;
+      orc_tq_attention_head(q.data() + h * d, kq + kvh * ms * pb, vq + kvh * ms * pb, pos + 1, d, bits, signs(kvh, 0), signs(kvh, 1), scale_tq,
+                            attn_tq.data() + h * d);
+    }
+    return linear_forward(m, L.wo, attn_tq.data(), out);
+  }
   float* kc = m->k_cache[li].data();
   float* vc = m->v_cache[li].data();
-  size_t ms = c.max_seq_len;
   if (m->kv_int8) {
     // QuantizedKVCache::write_kv + read_*_range with KVCacheFormat::Int8 (src/model/kv_quantized.rs:143-300): every head's row
     // of every position is stored as int8 with one scale; what attention later reads back is scale * q
@@ -317,6 +344,25 @@ int orc_model_finalize(orc_model* m) {
 void orc_model_reset(orc_model* m) { m->position = 0; }  // KVCache::reset (model/mod.rs:110-117): O(1)
 size_t orc_model_position(const orc_model* m) { return m->position; }
 
+// KVCacheType::TurboQuantMSE { bits } for this model: `signs` = [layers][kv heads][2][padded head_dim] (+1 / -1), the sign vectors
+// the reference would draw per (layer, head, k / v) engine (kv_turboquant.rs:44-71); bits 0 switches back to the f32 cache
+int orc_model_set_kv_turboquant(orc_model* m, int bits, const float* signs, size_t n_signs) {
+  if (bits == 0) { m->kv_tq_bits = 0; return 0; }
+  const orc_config& c = m->cfg;
+  const size_t pd = orc_tq_padded_dim(c.head_dim);
+  if ((bits != 2 && bits != 3) || !signs || n_signs != (size_t)c.num_layers * c.num_kv_heads * 2 * pd) return 1;
+  for (size_t i = 0; i < n_signs; i++)
+    if (signs[i] != 1.0f && signs[i] != -1.0f) return 1;
+  m->kv_tq_bits = bits;
+  m->kv_int8 = false;
+  m->kv_fp8 = 0;
+  m->tq_signs.assign(signs, signs + n_signs);
+  const size_t pb = orc_tq_packed_bytes(bits, pd);
+  m->tq_k.assign(c.num_layers, std::vector<uint8_t>((size_t)c.num_kv_heads * c.max_seq_len * pb));
+  m->tq_v = m->tq_k;
+  return 0;
+}
+
 void orc_model_set_kv_int8(orc_model* m, int on) { m->kv_int8 = on != 0; if (on) m->kv_fp8 = 0; }
 
 // quantize_int8 / dequantize_int8 (src/model/kv_quantized.rs:385-410): symmetric, scale = max|x| / 127 (1 when the row is
@@ -413,6 +459,12 @@ void orc_model_kv_shift_left(orc_model* m, size_t amount) {  // KVCache::shift_l
     for (auto* cache : {&m->k_cache[li], &m->v_cache[li]})
       for (size_t h = 0; h < c.num_kv_heads; h++)
         std::memmove(cache->data() + h * row_stride, cache->data() + h * row_stride + amount * c.head_dim, n * sizeof(float));
+  if (m->kv_tq_bits) {   // TurboQuantKVCache::shift_left (kv_turboquant.rs:245-266): the first `amount` entries of every head are drained
+    const size_t pb = orc_tq_packed_bytes(m->kv_tq_bits, orc_tq_padded_dim(c.head_dim)), rs = (size_t)c.max_seq_len * pb;
+    for (size_t li = 0; li < m->tq_k.size(); li++)
+      for (auto* cache : {&m->tq_k[li], &m->tq_v[li]})
+        for (size_t h = 0; h < c.num_kv_heads; h++) std::memmove(cache->data() + h * rs, cache->data() + h * rs + amount * pb, new_len * pb);
+  }
   m->position = new_len;   // the rows keep the RoPE rotation of their OLD positions (the reference does not re-rotate)
 }
 

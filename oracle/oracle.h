@@ -133,6 +133,23 @@ uint8_t orc_kv_quantize_fp8(int fmt, float value);
 float orc_kv_dequantize_fp8(int fmt, uint8_t bits);
 /* fmt 1 / 2: K/V rows pass through that format on their way into the cache; 0: off */
 void orc_model_set_kv_fp8(orc_model* m, int fmt);
+
+/* ---- TurboQuant KV cache (oracle/turboquant.cpp): what `--kv-cache-type tq2 | tq3` selects in the reference
+ * (src/config.rs:808-817; src/model/turboquant/{rotation,codebook,quant}.rs, src/model/kv_turboquant.rs).  The rotations' sign
+ * vectors are inputs (HadamardRotation::signs()); the QJL variants are not restated. */
+size_t orc_tq_padded_dim(size_t dim);
+int orc_tq_codebook(size_t dim, int bits, float* centroids, float* boundaries);
+uint8_t orc_tq_quantize(const float* boundaries, int bits, float val);
+size_t orc_tq_packed_bytes(int bits, size_t count);
+void orc_tq_quantize_vector(size_t dim, int bits, const float* data, size_t count, uint8_t* out);
+void orc_tq_dequantize_vector(size_t dim, int bits, const uint8_t* packed, size_t count, float* out);
+float orc_tq_dot_with_packed(size_t dim, int bits, const float* query, const uint8_t* packed, size_t count);
+void orc_tq_rotate(const float* x, size_t dim, const float* signs, float* out);
+void orc_tq_rotate_inverse(const float* x, size_t dim, const float* signs, float* out);
+void orc_tq_compress(const float* x, size_t dim, int bits, const float* signs, uint8_t* packed);
+void orc_tq_attention_head(const float* query, const uint8_t* k_codes, const uint8_t* v_codes, size_t kv_len, size_t dim, int bits,
+                           const float* signs_k, const float* signs_v, float scale, float* out);
+int orc_model_set_kv_turboquant(orc_model* m, int bits, const float* signs, size_t n_signs);
 /* debug taps: hidden state after the last forward's final layer (pre-norm) */
 int orc_model_last_hidden(const orc_model* m, float* out);
 

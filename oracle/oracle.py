@@ -75,6 +75,14 @@ def lib() -> C.CDLL:
         "orc_model_set_kv_int8": (None, [vp, C.c_int]), "orc_model_set_kv_fp8": (None, [vp, C.c_int]),
         "orc_kv_quantize_fp8": (C.c_uint8, [C.c_int, C.c_float]), "orc_kv_dequantize_fp8": (C.c_float, [C.c_int, C.c_uint8]),
         "orc_axpy_f32": (None, [C.c_float, vp, vp, sz]),
+        "orc_tq_padded_dim": (sz, [sz]), "orc_tq_codebook": (C.c_int, [sz, C.c_int, vp, vp]),
+        "orc_tq_quantize": (C.c_uint8, [vp, C.c_int, C.c_float]), "orc_tq_packed_bytes": (sz, [C.c_int, sz]),
+        "orc_tq_quantize_vector": (None, [sz, C.c_int, vp, sz, vp]), "orc_tq_dequantize_vector": (None, [sz, C.c_int, vp, sz, vp]),
+        "orc_tq_dot_with_packed": (C.c_float, [sz, C.c_int, vp, vp, sz]),
+        "orc_tq_rotate": (None, [vp, sz, vp, vp]), "orc_tq_rotate_inverse": (None, [vp, sz, vp, vp]),
+        "orc_tq_compress": (None, [vp, sz, C.c_int, vp, vp]),
+        "orc_tq_attention_head": (None, [vp, vp, vp, sz, sz, C.c_int, vp, vp, C.c_float, vp]),
+        "orc_model_set_kv_turboquant": (C.c_int, [vp, C.c_int, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
         "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),
         "orc_model_create": (vp, [C.POINTER(Config)]), "orc_model_destroy": (None, [vp]),
@@ -288,6 +296,77 @@ def kv_dequantize_int8(q, scale: float) -> np.ndarray:
 FP8_E4M3, FP8_E5M2 = 1, 2
 
 
+# ---- TurboQuant (oracle/turboquant.cpp; src/model/turboquant/*.rs, src/model/kv_turboquant.rs)
+def tq_padded_dim(dim: int) -> int:
+    return int(lib().orc_tq_padded_dim(dim))
+
+
+def tq_codebook(dim: int, bits: int):
+    """Codebook::new (codebook.rs:55-77): (centroids, boundaries), scaled by 1 / sqrt(dim)."""
+    c, b = np.zeros(1 << bits, np.float32), np.zeros((1 << bits) - 1, np.float32)
+    assert lib().orc_tq_codebook(dim, bits, _p(c), _p(b)) == 0
+    return c, b
+
+
+def tq_quantize(dim: int, bits: int, val: float) -> int:
+    _, b = tq_codebook(dim, bits)
+    return int(lib().orc_tq_quantize(_p(b), bits, C.c_float(val)))
+
+
+def tq_packed_bytes(bits: int, count: int) -> int:
+    return int(lib().orc_tq_packed_bytes(bits, count))
+
+
+def tq_quantize_vector(dim: int, bits: int, data) -> np.ndarray:
+    data = _f32(data)
+    out = np.zeros(tq_packed_bytes(bits, data.size), np.uint8)
+    lib().orc_tq_quantize_vector(dim, bits, _p(data), data.size, _p(out))
+    return out
+
+
+def tq_dequantize_vector(dim: int, bits: int, packed, count: int) -> np.ndarray:
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    out = np.zeros(count, np.float32)
+    lib().orc_tq_dequantize_vector(dim, bits, _p(packed), count, _p(out))
+    return out
+
+
+def tq_dot_with_packed(dim: int, bits: int, query, packed, count: int) -> float:
+    query, packed = _f32(query), np.ascontiguousarray(packed, dtype=np.uint8)
+    return float(lib().orc_tq_dot_with_packed(dim, bits, _p(query), _p(packed), count))
+
+
+def tq_rotate(x, signs) -> np.ndarray:
+    x, signs = _f32(x), _f32(signs)
+    out = np.zeros(tq_padded_dim(x.size), np.float32)
+    assert signs.size == out.size
+    lib().orc_tq_rotate(_p(x), x.size, _p(signs), _p(out))
+    return out
+
+
+def tq_rotate_inverse(x, dim: int, signs) -> np.ndarray:
+    x, signs = _f32(x), _f32(signs)
+    out = np.zeros(dim, np.float32)
+    lib().orc_tq_rotate_inverse(_p(x), dim, _p(signs), _p(out))
+    return out
+
+
+def tq_compress(x, bits: int, signs) -> np.ndarray:
+    x, signs = _f32(x), _f32(signs)
+    out = np.zeros(tq_packed_bytes(bits, tq_padded_dim(x.size)), np.uint8)
+    lib().orc_tq_compress(_p(x), x.size, bits, _p(signs), _p(out))
+    return out
+
+
+def tq_attention_head(query, k_codes, v_codes, kv_len: int, bits: int, signs_k, signs_v, scale: float) -> np.ndarray:
+    query = _f32(query)
+    k_codes, v_codes = np.ascontiguousarray(k_codes, dtype=np.uint8), np.ascontiguousarray(v_codes, dtype=np.uint8)
+    signs_k, signs_v = _f32(signs_k), _f32(signs_v)
+    out = np.zeros(query.size, np.float32)
+    lib().orc_tq_attention_head(_p(query), _p(k_codes), _p(v_codes), kv_len, query.size, bits, _p(signs_k), _p(signs_v), C.c_float(scale), _p(out))
+    return out
+
+
 def kv_quantize_fp8(fmt: int, x: float) -> int:
     """quantize_fp8_e4m3 / _e5m2 (kv_quantized.rs:413-449, 492-528): the byte."""
     return int(lib().orc_kv_quantize_fp8(fmt, C.c_float(x)))
@@ -328,6 +407,14 @@ class Model:
     def set_kv_int8(self, on: bool = True) -> None:
         """K/V rows go through the reference's int8 KV format (kv_quantized.rs) on their way into the cache."""
         lib().orc_model_set_kv_int8(self._h, int(on))
+
+    def set_kv_turboquant(self, bits: int, signs) -> None:
+        """KVCacheType::TurboQuantMSE { bits }: K/V rows are stored as TurboQuant codes and attention runs over the codes
+        (kv_turboquant.rs); `signs` = [layers][kv heads][2][padded head_dim] of +-1."""
+        signs = _f32(signs)
+        self._keep.append(signs)
+        if lib().orc_model_set_kv_turboquant(self._h, int(bits), _p(signs), signs.size):
+            raise ValueError("orc_model_set_kv_turboquant: bad bits / sign vector")
 
     def set_kv_fp8(self, fmt: int) -> None:
         """K/V rows go through one of the reference's FP8 KV formats (FP8_E4M3 / FP8_E5M2; 0 = off)."""

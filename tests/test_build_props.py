@@ -30,7 +30,7 @@ def _usage(src):
 
 
 def test_no_kernel_uses_scratch_or_spills_vgprs():
-    for src in ("matvec_mfma.hip", "prefill.hip", "attention.hip", "misc.hip", "dequant.hip"):
+    for src in ("matvec_mfma.hip", "matvec_batch.hip", "prefill.hip", "attention.hip", "attention_tq.hip", "misc.hip", "dequant.hip"):
         usage = _usage(src)
         assert usage, f"no kernels found in {src}"
         for fn, u in usage.items():

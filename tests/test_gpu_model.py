@@ -259,6 +259,62 @@ def test_full_size_llama3_8b_q4_k_m_matches_oracle(pkg, orc):
             eng.close()
 
 
+def test_the_bench_workload_itself_matches_the_oracle(pkg, orc):
+    """The workload bench.py times, compared with the ORACLE at full size: Llama-3-8B Q4_K_M, the bench's
+    128-token prompt (`i % 32000`, src/main.rs:1787) through prefill_token x 127 + forward — the f32 token-by-token path the
+    timed decode starts from — then 8 greedy steps at kv 129..136 (src/main.rs:1812-1822, src/model/llama.rs:275-362).  Both
+    sides are fed the ORACLE's greedy tokens; logits within 2e-3 * max|logit| + 2e-3 at every step, greedy tokens identical
+    wherever the oracle's top-1 / top-2 gap exceeds 4x the measured error.  The same prompt through the BATCHED prompt path
+    (f16 matrix-core GEMMs, the one place f16 rounding enters) against the same oracle logits: 1e-2 * max|logit| + 1e-2
+    (SURVEY.md 8c).  ~40 s of oracle time for the 128-token prompt."""
+    import os
+    cfg = pkg.make_config("llama-3-8b", max_seq_len=160)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors():
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    prompt = [i % 32000 % cfg.vocab_size for i in range(128)]
+    # the oracle parallelises over output columns like the reference's rayon loops (one task per output element, no cross-task
+    # reduction: the result does not depend on the thread count) — 136 full-size tokens need the box's cores
+    orc.set_threads(min(16, len(os.sched_getaffinity(0))))
+    try:
+        want = [ref.forward(prompt)]
+        toks = []
+        for _ in range(8):
+            toks.append(orc.argmax_last(want[-1]))
+            want.append(ref.forward([toks[-1]]))
+    finally:
+        orc.set_threads(1)
+    ref.close()
+    gaps = [float(np.sort(w)[-1] - np.sort(w)[-2]) for w in want]
+    for label, batched, tol in (("exact prompt path", False, lambda w: 2e-3 * float(np.abs(w).max()) + 2e-3),
+                                ("batched prompt path", True, lambda w: 1e-2 * float(np.abs(w).max()) + 1e-2)):
+        eng = pkg.HipGpuInference.from_model(model, 160, flags=0 if batched else pkg.hip_backend.FLAG_EXACT_PREFILL)
+        try:
+            if batched:
+                assert eng.prefill_is_batched()
+                eng.forward_batch(prompt[:-1])
+            else:
+                for t in prompt[:-1]:
+                    eng.prefill_token(t)
+            errs, same = [], 0
+            got = eng.forward(prompt[-1])
+            for i in range(9):
+                errs.append(float(np.abs(got - want[i]).max()))
+                assert errs[-1] <= tol(want[i]), f"{label}, step {i} (kv {128 + i}): max|dlogit| {errs[-1]:.3e} > {tol(want[i]):.3e}"
+                if gaps[i] > 4 * errs[-1]:
+                    assert orc.argmax_last(got) == orc.argmax_last(want[i]), f"{label}, step {i}: greedy token diverged (gap {gaps[i]:.3e}, err {errs[-1]:.3e})"
+                    same += 1
+                if i < 8:
+                    got = eng.forward(toks[i])
+            assert eng.position() == 136
+            print(f"bench workload vs oracle, {label}: max|dlogit| = {max(errs):.3e} (tol {tol(want[0]):.3e}), min gap {min(gaps):.3e}, "
+                  f"{same}/9 tokens decided and identical")
+        finally:
+            eng.close()
+
+
 def test_single_launch_and_split_attention_agree_across_the_switch(pkg, orc):
     """Decode attention runs as one launch per layer up to a context threshold and as split + combine beyond it (two
     graph variants, picked by the host-side position).  One engine switches at 64 rows in mid-sequence, one never uses
@@ -551,3 +607,97 @@ def test_quantized_kv_cache_follows_the_reference_formats(pkg, orc, name, mix, n
         ref.close()
 
 
+
+
+@pytest.mark.parametrize("name,mix,n_tok,bits", [("test-dense", "Q4_K_M", 70, 2), ("test-dense-d128", "Q4_K_M", 70, 2), ("test-dense-d128", "Q4_K_M", 70, 3),
+                                                 ("test-moe", "Q5_K_M", 40, 3), ("test-dense-d128", "Q4_K_M", 700, 2), ("test-dense", "Q8_0", 4000, 3)])
+def test_turboquant_kv_cache_follows_the_reference(pkg, orc, name, mix, n_tok, bits):
+    """KVCacheType::TurboQuantMSE { bits } — what the reference's `--kv-cache-type tq2 | tq3` selects (src/config.rs:808-817) — on
+    the device: K / V rows stored as rotated Lloyd-Max codes (src/model/turboquant/), attention over the codes
+    (src/model/kv_turboquant.rs:88-201 behind Backend::attention_turboquant, src/backend/mod.rs:240-264), against the oracle's
+    restatement with the SAME sign vectors on both sides (lgh_set_kv_rotation_signs <-> HadamardRotation::signs()), context 1 ...
+    4000.  The codes themselves are bit-exact (test_gpu_ops.py::test_turboquant_codes_bit_exact); a K / V element that differs
+    in its last f32 bits between device and oracle can fall into the neighbouring cell (a step of ~0.5-1 sigma of the rotated
+    coordinate), so the logit tolerance is 4x the f32 path's, as for the reference's FP8 caches.  The cache is 1/16 (2 bits) or
+    3/32 (3 bits) of the f32 one; shift_left / truncate move code rows (kv_turboquant.rs:236-266)."""
+    ktol = 4.0
+    max_seq = n_tok + 24
+    cfg = pkg.make_config(name, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=mix)
+    rng = np.random.default_rng(7 + bits)
+    signs = np.where(rng.integers(0, 2, cfg.num_layers * cfg.num_kv_heads * 2 * cfg.head_dim) == 1, 1.0, -1.0).astype(np.float32)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    ref.set_kv_turboquant(bits, signs)
+    kv_type = pkg.hip_backend.KV_TQ2 if bits == 2 else pkg.hip_backend.KV_TQ3
+    eng = pkg.HipGpuInference.from_model(model, max_seq, kv_cache_type=kv_type, kv_rotation_signs=signs)
+    f32 = pkg.HipGpuInference.from_model(model, max_seq)
+    assert eng.stats()["kv_bytes"] * 32 == f32.stats()["kv_bytes"] * bits
+    f32.close()
+    try:
+        toks = [(41 * i + 7) % cfg.vocab_size for i in range(n_tok)]
+        check = set(range(8)) | {n_tok // 2, n_tok - 2, n_tok - 1} | set(range(60, 68))
+        worst = 0.0
+        if n_tok > 500:
+            bulk = toks[:n_tok - 6]
+            for t in bulk:
+                eng.prefill_token(t)
+            ref.forward(bulk[:-1])
+            ref.forward(bulk[-1:])
+            toks = toks[n_tok - 6:]
+            check = set(range(6))
+        for i, t in enumerate(toks):
+            got, want = eng.forward(t), ref.forward([t])
+            if i in check:
+                worst = max(worst, float(np.abs(got - want).max()) / _tol(want))
+                assert np.abs(got - want).max() <= ktol * _tol(want), (i, float(np.abs(got - want).max()), _tol(want))
+        print(f"{name}/{mix} TurboQuant {bits}-bit KV, {eng.position()} rows: max|dlogit| = {worst:.4f} x the f32 tolerance")
+        if n_tok <= 500:
+            for e in (eng, ref):
+                e.kv_shift_left(11)
+            assert eng.position() == ref.position
+            for t in (5, 6, 7):
+                got, want = eng.forward(t), ref.forward([t])
+                assert np.abs(got - want).max() <= ktol * _tol(want)
+            eng.kv_truncate(20)
+            ref.kv_truncate(20)
+            got, want = eng.forward(9), ref.forward([9])
+            assert np.abs(got - want).max() <= ktol * _tol(want)
+            pos = eng.position()
+            dev = eng.decode_greedy(3, 8).tolist()                    # graph replays == the host loop
+            eng.kv_truncate(pos)
+            host, tok = [], 3
+            for _ in range(8):
+                tok = orc.argmax_last(eng.forward(tok))
+                host.append(tok)
+            assert dev == host
+    finally:
+        eng.close()
+        ref.close()
+
+
+def test_turboquant_sign_vector_contract(pkg):
+    """lgh_set_kv_rotation_signs: only +-1, exactly [layers][kv heads][2][head_dim] values, only on a TurboQuant context and only
+    before finalize; without it the context decodes with its deterministic stand-in; head sizes the butterfly cannot take are
+    refused at lgh_create."""
+    hb = pkg.hip_backend
+    cfg = pkg.make_config("test-dense-d128", max_seq_len=16)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    n = cfg.num_layers * cfg.num_kv_heads * 2 * cfg.head_dim
+    for bad in (np.ones(n - 1, np.float32), np.full(n, 0.5, np.float32)):
+        with pytest.raises(pkg.BackendError) as ei:
+            pkg.HipGpuInference.from_model(model, 16, kv_cache_type=hb.KV_TQ2, kv_rotation_signs=bad)
+        assert ei.value.variant == "InvalidArgument"
+    with pytest.raises(pkg.BackendError):
+        pkg.HipGpuInference.from_model(model, 16, kv_rotation_signs=np.ones(n, np.float32))      # an f32-cache context
+    eng = pkg.HipGpuInference.from_model(model, 16, kv_cache_type=hb.KV_TQ3)                      # stand-in signs
+    a = eng.forward(3)
+    eng.reset()
+    assert np.array_equal(a, eng.forward(3)) and np.all(np.isfinite(a))
+    eng.close()
+    with pytest.raises(pkg.BackendError) as ei:
+        pkg.HipGpuInference.from_model(pkg.SynthModel(pkg.make_config("test-dense", max_seq_len=16, head_dim=96), mix="Q4_K_M"), 16,
+                                       kv_cache_type=hb.KV_TQ2)
+    assert ei.value.variant in ("Unsupported", "InvalidArgument")

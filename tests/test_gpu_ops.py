@@ -206,3 +206,29 @@ def test_kv_cache_formats_bit_exact(gpu, orc, fmt):
         assert got_sc == np.float32(want_sc)
         assert np.array_equal(got_back.view(np.uint32)[~np.isnan(want_back)], want_back.view(np.uint32)[~np.isnan(want_back)])
         assert np.array_equal(np.isnan(got_back), np.isnan(want_back))
+
+
+@pytest.mark.parametrize("dim,bits", [(128, 2), (128, 3), (64, 2), (64, 3)])
+def test_turboquant_codes_bit_exact(gpu, orc, dim, bits):
+    """TurboQuantEngine::compress (src/model/turboquant/quant.rs:71-103 = rotation.rs:58-76 + codebook.rs:131-170) as the
+    attention launch applies it to a new K / V row (lgh_op_tq_compress): the packed codes equal the oracle's BIT FOR BIT — the
+    butterfly makes the same additions in the same order, the cell of a coordinate is the number of boundaries it is >=.
+    Rows of every scale (near-unit norm, tiny, saturating), a delta, a constant, zeros, and values sitting exactly ON a cell
+    boundary after rotation (a rotated delta has every coordinate at +-x / sqrt(d))."""
+    rng = np.random.default_rng(500 + dim + bits)
+    sign_sets = [np.where(rng.integers(0, 2, dim) == 1, 1.0, -1.0).astype(np.float32) for _ in range(3)] + [np.ones(dim, np.float32)]
+    rows = [rng.standard_normal(dim).astype(np.float32) * s for s in (1.0 / np.sqrt(dim), 1.0, 1e-4, 30.0)]
+    rows += [np.zeros(dim, np.float32), np.full(dim, 0.37, np.float32), (np.arange(dim, dtype=np.float32) - dim / 2) * np.float32(0.01)]
+    _, bnd = orc.tq_codebook(dim, bits)
+    for b in bnd:                                                    # delta * sqrt(d) * boundary: every rotated coordinate = +-boundary
+        e = np.zeros(dim, np.float32)
+        e[int(rng.integers(0, dim))] = np.float32(b) * np.sqrt(np.float32(dim))
+        rows.append(e)
+    n = 0
+    for sg in sign_sets:
+        for x in rows:
+            got, want = gpu.op_tq_compress(x, bits, sg), orc.tq_compress(x, bits, sg)
+            assert got.size == want.size == (dim // 4 if bits == 2 else dim // 8 * 3)
+            assert np.array_equal(got, want), (dim, bits, np.flatnonzero(got != want)[:4])
+            n += 1
+    assert n == 4 * len(rows)

@@ -332,3 +332,123 @@ def test_fp8_kv_cache_kats(orc):
     assert orc.kv_quantize_fp8(orc.FP8_E4M3, 500.0) == 0x7F and np.isnan(orc.kv_dequantize_fp8(orc.FP8_E4M3, 0x7F))
     assert orc.kv_quantize_fp8(orc.FP8_E4M3, 2.0 ** -10) == 0x00 and orc.kv_quantize_fp8(orc.FP8_E5M2, 2.0 ** -17) == 0x00
     assert orc.kv_quantize_fp8(orc.FP8_E4M3, float("nan")) == 0xFF and orc.kv_quantize_fp8(orc.FP8_E5M2, float("inf")) == 0x7C
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# TurboQuant KV cache (what `--kv-cache-type tq2 | tq3` selects): the reference's own unit tests of
+# src/model/turboquant/{codebook,rotation}.rs and src/model/kv_turboquant.rs, restated.  The rotation's sign vector is an
+# input of the oracle (the reference draws it from rand's StdRng, which is not restated): the tests that hold for ANY sign
+# vector run on deterministic +-1 patterns; test_deterministic / test_different_seeds_differ (rotation.rs:168-190) are about
+# the RNG stream itself and have no counterpart.
+# ---------------------------------------------------------------------------------------------------------------------
+def _signs(n, salt=0):
+    i = np.arange(n, dtype=np.uint64)
+    h = (i + np.uint64(salt) * np.uint64(7919)) * np.uint64(0x9E3779B97F4A7C15)
+    return np.where((h >> np.uint64(40)) & np.uint64(1), 1.0, -1.0).astype(np.float32)
+
+
+def test_turboquant_codebook_kats(orc):
+    """codebook.rs:277-348: 1-bit round trip, 2-bit ordering, vector quantize round trip, dot_with_packed consistency,
+    3-bit packing; plus the table constants themselves (codebook.rs:20-49) and packed_bytes (255-262)."""
+    c1, b1 = orc.tq_codebook(128, 1)                                                   # test_codebook_1bit_roundtrip
+    assert len(c1) == 2 and orc.tq_quantize(128, 1, -0.1) == 0 and orc.tq_quantize(128, 1, 0.1) == 1
+    assert c1[0] < 0 < c1[1] and abs(c1[0] + c1[1]) < 1e-6
+    c2, b2 = orc.tq_codebook(128, 2)                                                   # test_codebook_2bit_ordering
+    assert len(c2) == 4 and all(c2[i] < c2[i + 1] for i in range(3))
+    inv = np.float32(1.0) / np.sqrt(np.float32(128.0))
+    assert np.array_equal(c2, np.array([-1.5102326, -0.4528427, 0.4528427, 1.5102326], np.float32) * inv)
+    assert np.array_equal(b2, np.array([-0.98153765, 0.0, 0.98153765], np.float32) * inv)
+    c3, b3 = orc.tq_codebook(64, 3)
+    inv64 = np.float32(1.0) / np.sqrt(np.float32(64.0))
+    assert np.array_equal(c3, np.array([-2.1521645, -1.3441838, -0.7561303, -0.2453404, 0.2453404, 0.7561303, 1.3441838, 2.1521645], np.float32) * inv64)
+    assert np.array_equal(b3, np.array([-1.74817415, -1.05015705, -0.50073535, 0.0, 0.50073535, 1.05015705, 1.74817415], np.float32) * inv64)
+    # quantize = the number of boundaries the value is >= (boundaries ascending), the boundary itself goes up
+    for val, want in ((-1.0, 0), (float(b2[0]), 1), (np.nextafter(b2[0], np.float32(-1)).item(), 0), (0.0, 2), (1.0, 3)):
+        assert orc.tq_quantize(128, 2, val) == want
+    data = (np.arange(128, dtype=np.float32) - np.float32(64.0)) * np.float32(0.001)   # test_vector_quantize_roundtrip
+    packed = orc.tq_quantize_vector(128, 2, data)
+    assert packed.size == 32
+    deq = orc.tq_dequantize_vector(128, 2, packed, 128)
+    assert deq.size == 128 and np.all(np.abs(data - deq) < 0.1)
+    data = (np.arange(64, dtype=np.float32) - np.float32(32.0)) * np.float32(0.005)    # test_dot_with_packed_consistency
+    query = np.arange(64, dtype=np.float32) * np.float32(0.01)
+    packed = orc.tq_quantize_vector(64, 2, data)
+    deq = orc.tq_dequantize_vector(64, 2, packed, 64)
+    direct = np.float32(0.0)
+    for a, b in zip(query, deq):
+        direct = np.float32(direct + np.float32(a * b))
+    assert abs(float(direct) - orc.tq_dot_with_packed(64, 2, query, packed, 64)) < 1e-5
+    data = (np.arange(16, dtype=np.float32) - np.float32(8.0)) * np.float32(0.02)      # test_3bit_packing
+    packed = orc.tq_quantize_vector(16, 3, data)
+    assert packed.size == orc.tq_packed_bytes(3, 16) == 6
+    assert orc.tq_dequantize_vector(16, 3, packed, 16).size == 16
+    # the 3-bit stream: index i sits at bits [3i, 3i + 3) of its group's 24-bit little-endian word
+    idx = [orc.tq_quantize(16, 3, float(v)) for v in data]
+    for g in range(2):
+        word = int(packed[3 * g]) | int(packed[3 * g + 1]) << 8 | int(packed[3 * g + 2]) << 16
+        assert [(word >> (3 * i)) & 7 for i in range(8)] == idx[8 * g: 8 * g + 8]
+    assert [orc.tq_packed_bytes(b, n) for b, n in ((1, 128), (1, 9), (2, 128), (2, 5), (3, 128), (3, 9))] == [16, 2, 32, 2, 48, 6]
+
+
+def test_turboquant_rotation_kats(orc):
+    """rotation.rs:141-229: round trip (128), norm preservation (64), non-power-of-two round trips (3 ... 100) and norm
+    preservation (80), with the reference's inputs and tolerances; plus the butterfly itself on a delta (every output +-1/sqrt(d))."""
+    x = np.arange(128, dtype=np.float32) * np.float32(0.01) - np.float32(0.64)         # test_roundtrip
+    s = _signs(128, 42)
+    rot = orc.tq_rotate(x, s)
+    assert rot.size == 128 and np.all(np.abs(orc.tq_rotate_inverse(rot, 128, s) - x) < 1e-4)
+    x = np.arange(64, dtype=np.float32) * np.float32(0.02) - np.float32(0.64)          # test_norm_preservation
+    rot = orc.tq_rotate(x, _signs(64, 123))
+    assert abs(float(np.sqrt(np.sum(x * x))) - float(np.sqrt(np.sum(rot * rot)))) < 1e-3
+    for dim in (3, 5, 7, 10, 13, 17, 33, 65, 80, 96, 100):                             # test_non_power_of_two_roundtrip
+        pd = orc.tq_padded_dim(dim)
+        assert pd >= dim and pd & (pd - 1) == 0 and (pd == 1 or pd // 2 < dim)
+        x = np.arange(dim, dtype=np.float32) * np.float32(0.01) - np.float32(0.5)
+        s = _signs(pd, dim)
+        rot = orc.tq_rotate(x, s)
+        assert rot.size == pd and np.all(np.abs(orc.tq_rotate_inverse(rot, dim, s) - x) < 1e-3), dim
+    x = np.arange(80, dtype=np.float32) * np.float32(0.02) - np.float32(0.8)           # test_non_power_of_two_norm_preservation
+    rot = orc.tq_rotate(x, _signs(128, 123))
+    assert abs(float(np.sqrt(np.sum(x * x))) - float(np.sqrt(np.sum(rot * rot)))) < 1e-3
+    e = np.zeros(8, np.float32); e[3] = 1.0                                            # H D e_3: column 3 of the Hadamard matrix, signed
+    s = np.array([1, -1, 1, 1, -1, 1, -1, 1], np.float32)
+    want = np.array([(-1) ** bin(i & 3).count("1") for i in range(8)], np.float32) * s[3] / np.sqrt(np.float32(8))
+    assert np.allclose(orc.tq_rotate(e, s), want, atol=0, rtol=0)
+
+
+def test_turboquant_kv_cache_kats(orc):
+    """kv_turboquant.rs:289-428 on the cache the oracle's model path uses: attention over compressed K / V is finite and points
+    the right way (test_attention_direction, test_attention_layer_multi_head), the 2-bit cache is < 25 % of f32
+    (test_memory_savings); write / truncate / shift_left bookkeeping is covered at model level (tests/test_gpu_model.py)."""
+    dim, bits = 64, 2
+    sk, sv = _signs(64, 1), _signs(64, 2)
+    k_sim = np.arange(64, dtype=np.float32) * np.float32(0.01)                         # head 0 of the reference's 4 x 64 rows
+    k_opp = -k_sim
+    v1, v2 = np.full(64, 1.0, np.float32), np.full(64, 2.0, np.float32)
+    kc = np.concatenate([orc.tq_compress(k_sim, bits, sk), orc.tq_compress(k_opp, bits, sk)])
+    vc = np.concatenate([orc.tq_compress(v1, bits, sv), orc.tq_compress(v2, bits, sv)])
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(64.0)))
+    out = orc.tq_attention_head(k_sim, kc, vc, 2, bits, sk, sv, scale)
+    assert out.size == 64 and np.all(np.isfinite(out))
+    # (the reference asserts no more than the length here: its rows are far from unit norm, where a 2-bit codebook saturates)
+    # the softmax over the two positions: the output is the convex combination of the two decompressed value rows
+    rq = orc.tq_rotate(k_sim, sk)
+    s0, s1 = (np.float32(orc.tq_dot_with_packed(64, bits, rq, kc[16 * i: 16 * i + 16], 64)) * np.float32(scale) for i in range(2))
+    assert s0 > s1                                                                      # the query IS the first key
+    d = [orc.tq_rotate_inverse(orc.tq_dequantize_vector(64, bits, vc[16 * i: 16 * i + 16], 64), 64, sv) for i in range(2)]
+    e = np.exp(np.array([s0, s1], np.float32) - max(s0, s1))
+    w = e / np.float32(e[0] + e[1])
+    assert np.allclose(out, w[0] * d[0] + w[1] * d[1], rtol=1e-6, atol=1e-7)
+    k = np.full(64, 0.5, np.float32)                                                   # test_attention_layer_multi_head: one position
+    out = orc.tq_attention_head(k, orc.tq_compress(k, bits, sk), orc.tq_compress(np.full(64, 1.0, np.float32), bits, sv), 1, bits, sk, sv, scale)
+    assert np.all(np.isfinite(out))
+    # one position: softmax weight 1 -> the output is the decompressed value row itself
+    v = np.linspace(-1, 1, 64).astype(np.float32)
+    vcodes = orc.tq_compress(v, bits, sv)
+    want = orc.tq_rotate_inverse(orc.tq_dequantize_vector(64, bits, vcodes, 64), 64, sv)
+    assert np.array_equal(orc.tq_attention_head(k, orc.tq_compress(k, bits, sk), vcodes, 1, bits, sk, sv, scale), want)
+    assert orc.tq_packed_bytes(2, 128) * 2 * 4 * 2 < (128 * 4 * 2 * 4 * 2) // 4                                  # test_memory_savings
+    # compress = rotate + quantize_vector (quant.rs:71-103)
+    x = (np.arange(64, dtype=np.float32) - np.float32(32.0)) * np.float32(0.01)         # test_mse_compress_decompress input
+    assert np.array_equal(orc.tq_compress(x, 2, sk), orc.tq_quantize_vector(64, 2, orc.tq_rotate(x, sk)))
+    assert orc.tq_compress(x, 3, sk).size == 24
