@@ -300,6 +300,12 @@ int lgh_stage_hidden_block_buffer(lgh_ctx* ctx, void** device_ptr);
  * the last stage's arg-max lands in (int32 each).  The host side moves argmax_out -> token_in with an RCCL send/recv or a
  * peer copy on the stages' streams. */
 int lgh_stage_io_buffers(lgh_ctx* ctx, void** token_in, void** argmax_out);
+/* Stages that share a DEVICE and a stream (lgh_set_stream) can hop inside the producing stage's graph: from now on every token
+ * of `ctx` ends with hidden -> *hidden_dst (the next stage's lgh_stage_hidden_buffer; not the last stage) and, in mode 2,
+ * arg-max -> *token_dst (the first stage's token_in; last stage only).  NULL switches a hop off.  Both addresses must be memory
+ * of ctx's device.  Measured on one MI355X: a hop as a runtime copy between two graph launches costs 12-18 us, as a graph node
+ * 3 us (profiles/r03d_pipeline_boundary.md). */
+int lgh_stage_set_forward_targets(lgh_ctx* ctx, void* hidden_dst, void* token_dst);
 /* lgh_stage_forward without any host value: the token is already in *token_in (first stage) / the hidden vector in the
  * stage's hidden buffer; nothing is copied back and nothing is waited for.  mode 0 = this stage's layers only, 1 = + final
  * norm and output projection (last stage), 2 = + device arg-max into *argmax_out and the token log (last stage). */

@@ -223,6 +223,7 @@ hipError_t silu_mul_launch(const float* gate, const float* up, float* out, uint3
 hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* part_idx, int* state, int* out_token,
                          hipStream_t st);
 hipError_t advance_launch(int* state, hipStream_t st);
+hipError_t copy_words_launch(void* dst, const void* src, uint32_t n_words, hipStream_t st);
 hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
                              uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st, uint32_t n_tokens = 1);
 

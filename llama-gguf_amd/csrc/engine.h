@@ -80,6 +80,7 @@ struct lgh_ctx {
   lgh::DevWeight output;
   float* output_norm = nullptr;
   // scratch (device)
+  void *fwd_hidden = nullptr, *fwd_token = nullptr;   // in-graph hops to a same-device stage (lgh_stage_set_forward_targets)
   float *hidden = nullptr, *xnorm = nullptr, *q = nullptr, *kv_tmp = nullptr, *attn_out = nullptr, *act = nullptr,
         *act2 = nullptr, *logits = nullptr, *part_ml = nullptr, *part_acc = nullptr, *rope_cs = nullptr, *moe_w = nullptr,
         *amax_v = nullptr;

@@ -678,6 +678,13 @@ static int enqueue_token(lgh_ctx* c, int mode) {
         return rc;
     }
   }
+  // in-graph hops to a stage on the same device (lgh_stage_set_forward_targets)
+  if (c->fwd_hidden && !c->last &&
+      (rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, (uint64_t)d.hidden_size * 8, [&] { return copy_words_launch(c->fwd_hidden, c->hidden, d.hidden_size, c->stream); })))
+    return rc;
+  if (c->fwd_token && c->last && mode == MODE_GREEDY &&
+      (rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 8, [&] { return copy_words_launch(c->fwd_token, c->state + ST_ARGMAX, 1, c->stream); })))
+    return rc;
   return LGH_OK;
 }
 
@@ -740,6 +747,15 @@ static int step(lgh_ctx* c, int mode) {
   c->pos += 1;
   c->stats.tokens_processed += 1;
   return LGH_OK;
+}
+
+static void drop_graphs(lgh_ctx* c) {
+  for (int m = 0; m < MODE_COUNT; m++)
+    for (int v = 0; v < 2; v++)
+      if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
+  for (auto& gg : c->batch.graph)
+    for (auto& ge : gg)
+      if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
 }
 
 static int bind(const lgh_ctx* c) { return hipSetDevice(c->device) == hipSuccess ? LGH_OK : LGH_NOT_AVAILABLE; }
@@ -1523,15 +1539,25 @@ int lgh_set_stream(lgh_ctx* c, void* s) {
   if (bind(c)) return LGH_NOT_AVAILABLE;
   (void)hipStreamSynchronize(c->stream);
   hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
-  if (ns != c->stream) {
-    for (int m = 0; m < MODE_COUNT; m++)
-      for (int v = 0; v < 2; v++)
-        if (c->graph[m][v]) { (void)hipGraphExecDestroy(c->graph[m][v]); c->graph[m][v] = nullptr; }
-    for (auto& gg : c->batch.graph)
-      for (auto& ge : gg)
-        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
-  }
+  if (ns != c->stream) drop_graphs(c);
   c->stream = ns;
+  return LGH_OK;
+}
+
+int lgh_stage_set_forward_targets(lgh_ctx* c, void* hidden_dst, void* token_dst) {
+  int rc = check_ready(c);
+  if (rc) return rc;
+  if (hidden_dst && c->last) return fail(c, LGH_INVALID_ARGUMENT, "the last stage hands no hidden vector on");
+  if (token_dst && !c->last) return fail(c, LGH_INVALID_ARGUMENT, "only the last stage produces the arg-max token");
+  if (hidden_dst == c->hidden) return fail(c, LGH_INVALID_ARGUMENT, "hidden_dst is this stage's own buffer");
+  (void)hipStreamSynchronize(c->stream);
+  if (hidden_dst != c->fwd_hidden || token_dst != c->fwd_token) drop_graphs(c);
+  c->fwd_hidden = hidden_dst;
+  c->fwd_token = token_dst;
+  // first launch outside any capture (see warm_kernels); what it copies is overwritten before anything reads it
+  if (hidden_dst) HIP_TRY(c, LGH_OPERATION_FAILED, copy_words_launch(hidden_dst, c->hidden, c->d.hidden_size, c->stream));
+  if (token_dst) HIP_TRY(c, LGH_OPERATION_FAILED, copy_words_launch(token_dst, c->state + ST_ARGMAX, 1, c->stream));
+  HIP_TRY(c, LGH_OPERATION_FAILED, hipStreamSynchronize(c->stream));
   return LGH_OK;
 }
 

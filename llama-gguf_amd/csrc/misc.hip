@@ -295,6 +295,17 @@ hipError_t advance_launch(int* state, hipStream_t st) {
   return hipGetLastError();
 }
 
+// same-device pipeline hop (hidden vector / token word) as a graph node of the producing stage
+__global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+hipError_t copy_words_launch(void* dst, const void* src, uint32_t n, hipStream_t st) {
+  hipLaunchKernelGGL(copy_words_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (uint32_t*)dst, (const uint32_t*)src, n);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // MoE router (moe.rs:128-198; CUDA path gpu_only.rs:1765-1831 does this on the HOST after a D2H):
 // logits[e] = <rms_norm(h), W_r[e]>, stable descending sort, top-k, softmax over the k logits.

@@ -8,10 +8,14 @@
 // final norm + output projection on the last, src/distributed/model.rs:22-27), and per token and stage boundary ONE
 // `hipMemcpyPeerAsync` of f32[hidden] on the producing stage's stream + an event the consuming stage's stream waits for.
 // The host only enqueues: no host value crosses a stage boundary per token, and `lgh_pipeline_decode_greedy` synchronises
-// once, at the end.  (The multi-process form of the same pipeline — one rank per GPU, RCCL send/recv — is
+// once, at the end.  Stages that share a device share ONE stream and hop inside the producing stage's graph (no events, no runtime copies).
+// (The multi-process form of the same pipeline — one rank per GPU, RCCL send/recv — is
 // llama-gguf_amd/pipeline.py; both drive the same stage entry points.)
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -58,28 +62,39 @@ void split_layers(uint32_t n_layers, int n_stages, int s, uint32_t* lo, uint32_t
 
 hipStream_t stream_of(lgh_ctx* c) { return (hipStream_t)lgh_get_stream(c); }
 
+int copy_words(lgh_pipeline* p, void* dst, int dst_dev, const void* src, int src_dev, uint32_t n, hipStream_t st) {
+  PIPE_HIP(p, hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, (size_t)n * 4, st));
+  return LGH_OK;
+}
+
 // stage s has produced its output on its stream: hand it to stage s + 1.  A stage's hidden buffer is its residual stream for
 // the whole token, so the copy of token t + 1 into it waits until stage s + 1 has finished token t (without token feedback — a
 // prompt — nothing else holds an early stage back).
-int hand_over(lgh_pipeline* p, size_t s) {
+// `fed_back`: the token being enqueued was produced by the previous token's LAST stage (greedy decode): the first stage cannot
+// start it before every stage has finished the previous one, so the back-pressure wait is implied and skipped — a wait across
+// two streams costs tens of microseconds of GPU idle time (measured: 2 stages on one GPU 1.90 vs 1.63 ms per token with three
+// cross-stream waits per token; r03 DESIGN.md §6).  Stages that share a stream (same device) need no events at all.
+int hand_over(lgh_pipeline* p, size_t s, bool fed_back) {
   PIPE_HIP(p, hipSetDevice(p->device[s]));
-  hipStream_t st = stream_of(p->stage[s]);
-  if (p->consumed_set[s]) PIPE_HIP(p, hipStreamWaitEvent(st, p->consumed[s], 0));
-  PIPE_HIP(p, hipMemcpyPeerAsync(p->hidden[s + 1], p->device[s + 1], p->hidden[s], p->device[s], (size_t)p->hidden_size * 4, st));
+  hipStream_t st = stream_of(p->stage[s]), nx = stream_of(p->stage[s + 1]);
+  if (p->consumed_set[s] && !fed_back && st != nx) PIPE_HIP(p, hipStreamWaitEvent(st, p->consumed[s], 0));
+  if (st == nx) return LGH_OK;   // same device: the hop is a node of stage s's graph (lgh_stage_set_forward_targets)
+  if (int rc = copy_words(p, p->hidden[s + 1], p->device[s + 1], p->hidden[s], p->device[s], p->hidden_size, st)) return rc;
   PIPE_HIP(p, hipEventRecord(p->handed[s], st));
   PIPE_HIP(p, hipSetDevice(p->device[s + 1]));
-  PIPE_HIP(p, hipStreamWaitEvent(stream_of(p->stage[s + 1]), p->handed[s], 0));
+  PIPE_HIP(p, hipStreamWaitEvent(nx, p->handed[s], 0));
   return LGH_OK;
 }
 
 // One token through all stages, nothing synchronised.  mode_last: what the last stage does (0 layers only, 1 + logits, 2 + arg-max).
-int run_token(lgh_pipeline* p, int mode_last) {
+int run_token(lgh_pipeline* p, int mode_last, bool fed_back = false) {
   const size_t n = p->stage.size();
   for (size_t s = 0; s < n; s++) {
     int rc = lgh_stage_step(p->stage[s], s + 1 == n ? mode_last : 0);
     if (rc) return stage_fail(p, s, rc);
-    if (s + 1 < n && (rc = hand_over(p, s))) return rc;
-    if (s > 0) {   // this stage's token is out of its hidden buffer (copied on, or — the last stage — fully processed)
+    if (s + 1 < n && (rc = hand_over(p, s, fed_back))) return rc;
+    if (s > 0 && stream_of(p->stage[s]) != stream_of(p->stage[s - 1])) {
+      // this stage's token is out of its hidden buffer (copied on, or — the last stage — fully processed)
       PIPE_HIP(p, hipSetDevice(p->device[s]));
       PIPE_HIP(p, hipEventRecord(p->consumed[s - 1], stream_of(p->stage[s])));
       p->consumed_set[s - 1] = true;
@@ -153,9 +168,23 @@ int lgh_pipeline_finalize(lgh_pipeline* p) {
     if (rc) return stage_fail(p, s, rc);
     if ((rc = lgh_stage_hidden_buffer(p->stage[s], &p->hidden[s]))) return stage_fail(p, s, rc);
   }
+  // stages on one device run on ONE stream (in order, no events between them); the first such stage's stream is the device's
+  for (size_t s = 1; s < n; s++)
+    for (size_t t = 0; t < s; t++)
+      if (p->device[t] == p->device[s]) {
+        const int rs = lgh_set_stream(p->stage[s], lgh_get_stream(p->stage[t]));
+        if (rs) return stage_fail(p, s, rs);
+        break;
+      }
   int rc = lgh_stage_io_buffers(p->stage[0], &p->token_in, nullptr);
   if (rc) return stage_fail(p, 0, rc);
   if ((rc = lgh_stage_io_buffers(p->stage[n - 1], nullptr, &p->argmax_out))) return stage_fail(p, n - 1, rc);
+  // ... and hop inside the producing stage's graph
+  for (size_t s = 0; s < n && n > 1; s++) {
+    void* hd = s + 1 < n && p->device[s] == p->device[s + 1] ? p->hidden[s + 1] : nullptr;
+    void* td = s + 1 == n && p->device[s] == p->device[0] ? p->token_in : nullptr;
+    if ((hd || td) && (rc = lgh_stage_set_forward_targets(p->stage[s], hd, td))) return stage_fail(p, s, rc);
+  }
   // direct peer copies between neighbouring stages (and last -> first for the token); "already enabled" is fine
   for (size_t s = 0; s < n; s++) {
     const int a = p->device[s], b = p->device[(s + 1) % n];
@@ -223,17 +252,23 @@ int lgh_pipeline_decode_greedy(lgh_pipeline* p, uint32_t first_token, size_t n_s
   const size_t n = p->stage.size(), pos0 = p->pos;
   int rc = set_token(p, first_token);
   if (rc) return rc;
+  const auto t_host0 = std::chrono::steady_clock::now();
   for (size_t i = 0; i < n_steps; i++) {
-    if ((rc = run_token(p, 2))) return rc;
+    if ((rc = run_token(p, 2, i > 0))) return rc;
     if (n > 1) {   // the arg-max word -> the first stage's token word, device to device, behind the last stage's kernels
       PIPE_HIP(p, hipSetDevice(p->device[n - 1]));
-      hipStream_t st = stream_of(p->stage[n - 1]);
-      PIPE_HIP(p, hipMemcpyPeerAsync(p->token_in, p->device[0], p->argmax_out, p->device[n - 1], 4, st));
-      PIPE_HIP(p, hipEventRecord(p->token_back, st));
-      PIPE_HIP(p, hipSetDevice(p->device[0]));
-      PIPE_HIP(p, hipStreamWaitEvent(stream_of(p->stage[0]), p->token_back, 0));
+      hipStream_t st = stream_of(p->stage[n - 1]), s0 = stream_of(p->stage[0]);
+      if (st != s0) {   // (same stream: the last stage's graph ends with the copy)
+        if ((rc = copy_words(p, p->token_in, p->device[0], p->argmax_out, p->device[n - 1], 1, st))) return rc;
+        PIPE_HIP(p, hipEventRecord(p->token_back, st));
+        PIPE_HIP(p, hipSetDevice(p->device[0]));
+        PIPE_HIP(p, hipStreamWaitEvent(s0, p->token_back, 0));
+      }
     }
   }
+  if (std::getenv("LGH_DEBUG_PIPE") && n_steps)   // how long the HOST took to enqueue the steps (nothing synchronised yet)
+    std::fprintf(stderr, "[lgh] pipeline: %zu steps x %zu stages enqueued in %.1f us per step\n", n_steps, n,
+                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count() / (double)n_steps);
   if ((rc = lgh_stage_read_tokens(p->stage[n - 1], pos0, n_steps, tokens_out))) return stage_fail(p, n - 1, rc);
   return sync_all(p);
 }

@@ -31,7 +31,7 @@ ABI_SYMBOLS = (
     "lgh_read_hidden", "lgh_stage_hidden_buffer", "lgh_stage_forward", "lgh_op_dequantize", "lgh_op_vec_mat",
     "lgh_op_rms_norm", "lgh_op_rope", "lgh_op_attention_cached", "lgh_op_silu_mul", "lgh_op_norm_vec_mat",
     "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
-    "lgh_stage_io_buffers", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get", "lgh_stage_read_logits",
+    "lgh_stage_io_buffers", "lgh_stage_set_forward_targets", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get", "lgh_stage_read_logits",
     "lgh_pipeline_create", "lgh_pipeline_upload_tensor", "lgh_pipeline_finalize", "lgh_pipeline_destroy", "lgh_pipeline_forward",
     "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_stages",
     "lgh_pipeline_last_error",
@@ -149,7 +149,7 @@ def load_library() -> C.CDLL:
         "lgh_bench_hbm_read": (C.c_int, [C.c_int, sz, C.c_int, C.POINTER(C.c_double)]),
         "lgh_gguf_inspect": (C.c_int, [C.c_char_p, C.POINTER(GgufInfo), C.c_char_p, sz]),
         "lgh_load_gguf": (C.c_int, [C.c_char_p, u32, C.c_int, u32, u32, u32, C.POINTER(vp), C.c_char_p, sz]),
-        "lgh_stage_io_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]), "lgh_stage_step": (C.c_int, [vp, C.c_int]),
+        "lgh_stage_io_buffers": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]), "lgh_stage_set_forward_targets": (C.c_int, [vp, vp, vp]), "lgh_stage_step": (C.c_int, [vp, C.c_int]),
         "lgh_stage_read_tokens": (C.c_int, [vp, sz, sz, vp]),
         "lgh_gguf_get": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(GgufValue), C.c_char_p, sz]),
         "lgh_stage_read_logits": (C.c_int, [vp, vp]),

@@ -76,6 +76,66 @@ __global__ void __launch_bounds__(512) k_mv_stream(const unsigned char* __restri
   if (wave == 0) st[b].t1 = __builtin_amdgcn_s_memrealtime();
 }
 
+// The same stream through an LDS ring filled by LDS-DMA ("weight stream by LDS-DMA nt into an LDS ring"): every
+// wave keeps RING tiles of 2304 B in flight in its own 16 KB of LDS (8 waves x 7 tiles = 126 KB per CU against the 72 KB the
+// register version holds), waits for the oldest with a counted vmcnt, reads it back with three ds_read_b128 / b32 per lane (what
+// a consumer would do) and refills the slot.  NT: non-temporal DMA (aux nt).
+template <int RING, bool NT>
+__global__ void __launch_bounds__(512) k_mv_stream_lds(const unsigned char* __restrict__ w, unsigned tiles_total, unsigned nblk, unsigned tb,
+                                                       unsigned R, unsigned npass, ull plane, float* sink, Stamp* st) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned b = blockIdx.x;
+  if (wave == 0) { st[b].t0 = __builtin_amdgcn_s_memrealtime(); st[b].xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xF; }
+  const unsigned nbw = nblk / 8, blk0 = wave * nbw;
+  const unsigned nitems = npass * R * nbw;
+  auto addr = [&](unsigned it) -> const unsigned char* {
+    if (it >= nitems) it = nitems - 1;
+    const unsigned p = it / (R * nbw), r = it % (R * nbw), j = r / nbw, bb = r % nbw;
+    unsigned t = b * R + j;
+    if (t >= tiles_total) t = tiles_total - 1;
+    return w + (ull)p * plane + ((ull)t * nblk + blk0 + bb) * tb;
+  };
+  constexpr unsigned kSlot = 2304;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + wave * RING * kSlot;
+  auto dma = [&](unsigned slot, const unsigned char* src) {
+    const unsigned dst = lds0 + slot * kSlot;
+    unsigned keep;
+    if (NT)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, off nt\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off nt\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 16), "v"(src + 2048 + lane * 4), "s"(dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %2, off\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + lane * 16), "v"(src + 1024 + lane * 16), "v"(src + 2048 + lane * 4), "s"(dst) : "memory");
+  };
+  u32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < RING; j++) dma(j, addr(j));
+  const unsigned char* my = smem + wave * RING * kSlot;
+  for (unsigned it = 0; it < nitems; it += RING) {
+#pragma unroll
+    for (int j = 0; j < RING; j++) {
+      // RING - 1 younger tiles (3 DMA instructions each) may stay in flight
+      if constexpr (RING == 7) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if constexpr (RING == 4) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const u32x4 a = *(const u32x4*)(my + j * kSlot + lane * 16);
+      const u32x4 c = *(const u32x4*)(my + j * kSlot + 1024 + lane * 16);
+      const unsigned h = *(const unsigned*)(my + j * kSlot + 2048 + lane * 4);
+      acc ^= a ^ c;
+      acc.x ^= h;
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc) :: "memory");   // the slot has been read: it may be refilled
+      dma(j, addr(it + RING + j));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[threadIdx.x] = 1.0f;
+  __syncthreads();
+  if (wave == 0) st[b].t1 = __builtin_amdgcn_s_memrealtime();
+}
+
 // a latency-bound interlude: 32 small workgroups that idle for `us` microseconds (the attention nodes between two mat-vecs)
 __global__ void k_idle(unsigned us, float* sink) {
   const ull t0 = __builtin_amdgcn_s_memrealtime();
@@ -156,6 +216,54 @@ int main() {
       std::printf("| %d | %.2f | %.2f | see below | %.2f / %.2f / %.2f | %.2f |\n", map, us, mat / us / 1e6, fst / reps, med / reps, lst / reps, mat / 256.0 / 24.6e3);
       for (auto& l : lines) std::printf("%s\n", l.c_str());
       std::fflush(stdout);
+    }
+  }
+  // ---- F: the same streams through LDS-DMA rings (7 or 4 tiles per wave; default policy or nt) against the register version
+  {
+    std::printf("\n## F. weight stream through an LDS-DMA ring vs registers (us per launch eager, cold copies; first / median / last workgroup end in-kernel)\n| shape | registers, 4 tiles/wave (nt) | LDS ring 4 (nt) | LDS ring 7 (default policy) | LDS ring 7 (nt) |\n|---|---|---|---|---|\n");
+    hipFuncSetAttribute((const void*)k_mv_stream_lds<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mv_stream_lds<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute((const void*)k_mv_stream_lds<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (const Cfg& c : cfgs) {
+      if (c.tb != 2304) continue;
+      const size_t plane = (size_t)c.tiles * c.nblk * c.tb, mat = plane * c.npass;
+      const size_t stride = (mat + (2u << 20) + 4095) / 4096 * 4096 + 4096 * 37;
+      const int copies = (int)std::min<size_t>(24, pool / stride);
+      std::printf("| %s |", c.name);
+      for (int v = 0; v < 4; v++) {
+        auto launch = [&](int i) {
+          const unsigned char* base = w + (size_t)(i % copies) * stride;
+          if (v == 0) hipLaunchKernelGGL(k_mv_stream, dim3(c.n_wg), dim3(512), 0, s, base, c.tiles, c.nblk, c.tb, c.R, c.npass, (ull)plane, 0, sink, st);
+          else if (v == 1) hipLaunchKernelGGL((k_mv_stream_lds<4, true>), dim3(c.n_wg), dim3(512), 8 * 4 * 2304, s, base, c.tiles, c.nblk, c.tb, c.R, c.npass, (ull)plane, sink, st);
+          else if (v == 2) hipLaunchKernelGGL((k_mv_stream_lds<7, false>), dim3(c.n_wg), dim3(512), 8 * 7 * 2304, s, base, c.tiles, c.nblk, c.tb, c.R, c.npass, (ull)plane, sink, st);
+          else hipLaunchKernelGGL((k_mv_stream_lds<7, true>), dim3(c.n_wg), dim3(512), 8 * 7 * 2304, s, base, c.tiles, c.nblk, c.tb, c.R, c.npass, (ull)plane, sink, st);
+        };
+        for (int i = 0; i < 5; i++) launch(i);
+        CHECK(hipStreamSynchronize(s));
+        const int iters = 48;
+        CHECK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; i++) launch(i + 5);
+        CHECK(hipEventRecord(e1, s));
+        CHECK(hipStreamSynchronize(s));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        double fst = 0, med = 0, lst = 0;
+        for (int r = 0; r < 4; r++) {
+          launch(r * 5 + 2);
+          CHECK(hipStreamSynchronize(s));
+          std::vector<Stamp> h(c.n_wg);
+          CHECK(hipMemcpy(h.data(), st, sizeof(Stamp) * c.n_wg, hipMemcpyDeviceToHost));
+          ull base = ~0ull;
+          for (auto& x : h) base = std::min(base, x.t0);
+          std::vector<double> all;
+          for (auto& x : h) all.push_back((double)(x.t1 - base) * 0.01);
+          std::sort(all.begin(), all.end());
+          fst += all.front() / 4; med += all[all.size() / 2] / 4; lst += all.back() / 4;
+        }
+        std::printf(" %.2f (%.2f / %.2f / %.2f) |", ms * 1000.0 / iters, fst, med, lst);
+        std::fflush(stdout);
+      }
+      std::printf("\n");
     }
   }
   // ---- E: does the skew come from what runs BEFORE a streaming launch?  One graph: 12 gate_up-sized launches (map 0), separated by

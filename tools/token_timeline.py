@@ -64,15 +64,37 @@ def main():
     ap.add_argument("--kv", type=int, default=128)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--layer", type=int, default=5, help="layer printed node by node")
+    ap.add_argument("--stages", type=int, default=0, help="the in-library pipeline with this many stages on device 0 (prints the gaps > 3 us of a token)")
     a = ap.parse_args()
     pkg = graft.load_package()
     cfg = pkg.make_config(a.model, max_seq_len=a.kv + a.steps + 64)
-    eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=a.mix), a.kv + a.steps + 64)
-    eng.forward_batch([t % cfg.vocab_size for t in range(a.kv)])
-    eng.decode_greedy(5, a.steps)
     lib = pkg.hip_backend.load_library()
     lib.lgh_debug_timeline.restype = C.c_longlong
     lib.lgh_debug_timeline.argtypes = [C.c_int, C.c_void_p]
+    if a.stages:
+        eng = pkg.HipPipeline.from_model(pkg.SynthModel(cfg, mix=a.mix), a.kv + a.steps + 64, a.stages, devices=[0] * a.stages)
+        for t in range(a.kv):
+            eng.prefill_token(t % cfg.vocab_size)
+        eng.decode_greedy(5, a.steps)
+        nodes = read_nodes(lib)
+        emb = [i for i, d in enumerate(nodes) if d["kind"] == "embed"]
+        tok = nodes[emb[-3]: emb[-2] + 1]
+        t0 = tok[0]["t0"].min()
+        print(f"# {a.model} {a.mix}, {a.stages} stages on one device: one token embed -> next embed {(tok[-1]['t0'].min() - t0) / 100.0:.1f} us, {len(tok) - 1} stamped nodes")
+        prev, idle = None, 0.0
+        for d in tok:
+            s0, e0 = d["t0"].min(), d["t1"].max()
+            if prev is not None:
+                gap = (s0 - prev) / 100.0
+                idle += max(gap - 1.6, 0.0)
+                if gap > 3.0:
+                    print(f"  +{(s0 - t0) / 100.0:9.2f} us  gap {gap:7.2f} before {d['kind']} (grid {d['grid']})")
+            prev = e0
+        print(f"  idle beyond 1.6 us per boundary: {idle:.1f} us")
+        return
+    eng = pkg.HipGpuInference.from_model(pkg.SynthModel(cfg, mix=a.mix), a.kv + a.steps + 64)
+    eng.forward_batch([t % cfg.vocab_size for t in range(a.kv)])
+    eng.decode_greedy(5, a.steps)
     nodes = read_nodes(lib)
     # the last complete token: from its embed node to its argmax2 node
     ends = [i for i, d in enumerate(nodes) if d["kind"] == "argmax2"]
