@@ -83,8 +83,8 @@ typedef struct lgh_model_desc {
   uint32_t layer_end;
   uint32_t flags;                    /* LGH_FLAG_* */
   uint32_t kv_cache_type;            /* LGH_KV_*.  What the reference's `--kv-cache-type` can select is KVCacheType::{F32, TurboQuantMSE,
-                                        TurboQuantProd} (src/config.rs:808-817): LGH_KV_F32, LGH_KV_TQ2, LGH_KV_TQ3 here (Prod = QJL: not
-                                        implemented).  LGH_KV_INT8 / FP8_* are the formats of QuantizedKVCache (src/model/kv_quantized.rs:
+                                        TurboQuantProd} (src/config.rs:808-817): LGH_KV_F32, LGH_KV_TQ2 / TQ3, LGH_KV_TQ2_QJL / TQ3_QJL here.
+                                        LGH_KV_INT8 / FP8_* are the formats of QuantizedKVCache (src/model/kv_quantized.rs:
                                         11-20), which the reference exports (model/mod.rs:31, lib.rs:77) but which NO forward path and no
                                         CLI flag of it reaches; they are offered for hosts that use that cache type directly.
                                         0 = f32, or int8 when LGH_FLAG_KV_INT8 is set (the field was added after the flag) */
@@ -97,9 +97,15 @@ enum {
   LGH_KV_FP8_E5M2 = 3,
   /* KVCacheType::TurboQuantMSE { bits } (src/model/mod.rs:182-213): what `--kv-cache-type turboquant2 | tq2` / `turboquant3 | tq3`
    * selects (src/config.rs:808-817) — randomized Hadamard rotation + Lloyd-Max scalar codes, src/model/turboquant/, cache and
-   * attention src/model/kv_turboquant.rs.  head_dim 64 or 128.  (The QJL variants tq2-qjl / tq3-qjl are not implemented.) */
+   * attention src/model/kv_turboquant.rs.  head_dim 64 or 128. */
   LGH_KV_TQ2 = 4,
   LGH_KV_TQ3 = 5,
+  /* KVCacheType::TurboQuantProd { bits }: `turboquant2-qjl | tq2-qjl` / `turboquant3-qjl | tq3-qjl` — the same codes plus, per K row,
+   * the sign bits of a Gaussian projection of the quantization residual and the residual's norm (QJL, src/model/turboquant/qjl.rs);
+   * scores = codes' dot product + the QJL correction (quant.rs:133-168).  The projection matrices are an input:
+   * lgh_set_kv_qjl_matrices. */
+  LGH_KV_TQ2_QJL = 6,
+  LGH_KV_TQ3_QJL = 7,
 };
 
 enum {
@@ -244,6 +250,17 @@ int lgh_set_kv_rotation_signs(lgh_ctx* ctx, const float* signs, size_t n);
 /* one row through the TurboQuant compressor (TurboQuantEngine::compress without QJL, src/model/turboquant/quant.rs:71-103):
  * x[dim] (dim 64 or 128), bits 2 or 3, signs[dim] -> codes[dim / 4 or dim / 8 * 3].  Bit-exact with the reference's arithmetic. */
 int lgh_op_tq_compress(int device, int bits, const float* x, size_t dim, const float* signs, uint8_t* codes);
+/* TurboQuantProd: the QJL projection matrices of the K engines, [owned layer][kv head][head_dim][head_dim] f32, row i = the i-th
+ * projection vector in the order QjlProjector draws it (src/model/turboquant/qjl.rs:44-52: StdRng::seed_from_u64(seed), one
+ * StandardNormal sample per (i, j), j fastest; the K engine's seed is 4 * (layer * kv_heads + head) + 1, kv_turboquant.rs:55-58).
+ * Call between lgh_create and lgh_finalize on a context with kv_cache_type LGH_KV_TQ2_QJL / TQ3_QJL; without it the library uses
+ * a deterministic stand-in (i.i.d. N(0, 1), but not the reference's RNG stream).  (The V engines' projectors are not needed: the
+ * reference never reads the QJL bits of V rows, kv_turboquant.rs:154-170.) */
+int lgh_set_kv_qjl_matrices(lgh_ctx* ctx, const float* matrices, size_t n);
+/* lgh_op_tq_compress with use_qjl (quant.rs:71-103): + qjl_matrix[dim][dim] -> qjl_bits[dim / 64] (bit i % 64 of word i / 64 =
+ * (S r)_i >= 0, r the residual) and *residual_norm.  Bit-exact with the reference's arithmetic for the given matrix. */
+int lgh_op_tq_compress_qjl(int device, int bits, const float* x, size_t dim, const float* signs, const float* qjl_matrix, uint8_t* codes,
+                           uint64_t* qjl_bits, float* residual_norm);
 
 /* ---- multi-sequence decode: the device side of BatchedEngine (src/engine_batched.rs:23-194, 200-330, 355-400) ----
  * The reference keeps one InferenceContext (KV cache + position) per ActiveSequence (engine_batched.rs:84-100, 332-353) and every

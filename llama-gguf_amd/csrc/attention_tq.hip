@@ -1,5 +1,6 @@
-// attention_tq.hip — decode attention over the reference's TurboQuant KV cache (KVCacheType::TurboQuantMSE { bits: 2 | 3 }: what
-// `--kv-cache-type turboquant2 | turboquant3 (tq2 | tq3)` selects, src/config.rs:808-817, src/model/mod.rs:182-213).
+// attention_tq.hip — decode attention over the reference's TurboQuant KV cache (KVCacheType::TurboQuantMSE { bits: 2 | 3 } and
+// TurboQuantProd { bits: 2 | 3 }: what `--kv-cache-type turboquant2 | turboquant3 (tq2 | tq3)` and `turboquant2-qjl | turboquant3-qjl
+// (tq2-qjl | tq3-qjl)` select, src/config.rs:808-817, src/model/mod.rs:182-213).
 //
 // Replaces Backend::attention_turboquant (src/backend/mod.rs:240-264; its CPU body TurboQuantKVCache::attention_layer,
 // src/model/kv_turboquant.rs:127-201; the reference's CUDA twin `turboquant_attention_2bit`, src/backend/cuda/kernels.rs:
@@ -29,7 +30,7 @@
 
 namespace lgh {
 
-struct TqTables { float cen[8]; float bnd[7]; float norm, inv_scale, inv_d; };   // host-computed (the oracle's own arithmetic)
+struct TqTables { float cen[8]; float bnd[7]; float norm, inv_scale, inv_d, qjl_coeff; };   // host-computed (the oracle's own arithmetic)
 
 template <int BITS>
 __device__ __forceinline__ uint32_t tq_quantize(const TqTables& T, float v) {   // codebook.rs:79-92 (boundaries ascending)
@@ -97,24 +98,77 @@ __device__ __forceinline__ void tq_pack_row(const TqTables& T, const float* y, u
   }
 }
 
+// QJL side of a new K row and of `nq` rotated queries (all 256 threads; LDS in, LDS out):
+//   res = y - dequantized codes of y (quant.rs:85-89);  newx = sign bits of S res, then |res| (QjlProjector::compress, qjl.rs:36-62);
+//   pq[r] = S xq[r] (project_query, qjl.rs:100-114).  Every dot product is the reference's loop: dot += s_ij * x[j] in order, unfused.
+template <int D, int BITS>
+__device__ __forceinline__ void tq_qjl_rows(const TqTables& T, const float* __restrict__ S, uint32_t nq, const float* xq, const float* y,
+                                            const uint8_t* codes, float* res, float* pq, uint32_t* newx) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  if (tid < D) res[tid] = y[tid] - tq_centroid<BITS>(T, tq_index<BITS>(codes, tid));
+  __syncthreads();
+  for (uint32_t e = tid; e < (nq + 1) * D; e += 256) {    // a wave's 64 lanes: one row r, 64 consecutive i (D is a multiple of 64)
+    const uint32_t r = e / D, i = e % D;
+    const float* x = r < nq ? xq + r * D : res;
+    const float4* srow = reinterpret_cast<const float4*>(S + (size_t)i * D);
+    float dot = 0.0f;
+#pragma unroll 8
+    for (uint32_t j4 = 0; j4 < (uint32_t)D / 4; j4++) {   // (8 row loads in flight: enough to cover L2, no register blow-up)
+      const float4 s4 = srow[j4];
+      dot += s4.x * x[4 * j4];
+      dot += s4.y * x[4 * j4 + 1];
+      dot += s4.z * x[4 * j4 + 2];
+      dot += s4.w * x[4 * j4 + 3];
+    }
+    if (r < nq) {
+      pq[r * D + i] = dot;
+    } else {
+      const unsigned long long b = __ballot(dot >= 0.0f);              // bit (i % 64) of word i / 64 (qjl.rs:58-60)
+      if (lane == 0) { newx[(i >> 6) * 2] = (uint32_t)b; newx[(i >> 6) * 2 + 1] = (uint32_t)(b >> 32); }
+    }
+  }
+  if (tid == 255) {                                                    // l2_norm (qjl.rs:180-182): sequential sum of squares
+    float ss = 0.0f;
+    for (uint32_t i = 0; i < (uint32_t)D; i++) ss += res[i] * res[i];
+    newx[D / 32] = __float_as_uint(sqrtf(ss));
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // split attention over the code caches.  grid = n_kv * n_splits, 256 threads.
 // signs: this layer's [kv head][k, v][D]; k_new / v_new: the current token's f32 rows [kv head][D]
-// dynamic LDS: (G + 2) * D floats (rotated queries, the current K row, the current V row) + 2 * row bytes (its codes, 16-aligned)
-//              + G * cap floats (scores of this split's positions) + 64 floats of reduction scratch
+// dynamic LDS: (G + 2) * D floats (rotated queries, the current K row, the current V row) [QJL: + (G + 1) * D floats: the projected
+//              queries S (H D q) and the residual of the current K row] + 2 * row bytes (its codes, 16-aligned) + 32 bytes (its QJL
+//              row) + G * cap floats (scores of this split's positions) + 64 floats of reduction scratch
+//
+// QJL = KVCacheType::TurboQuantProd (`tq2-qjl | tq3-qjl`; src/model/turboquant/qjl.rs, quant.rs:71-168): a K row additionally keeps
+// the sign bits of S r — r = rotated row - its dequantized codes, S the engine's d x d Gaussian projection (an INPUT of the library,
+// lgh_set_kv_qjl_matrices: [kv head][D][D] for this layer) — and |r|; its score is the codes' dot product PLUS
+// sqrt(pi / 2) / d * |r| * sum_i (S H D q)_i * sign_i.  Bits, norms and projected queries are computed with the reference's own
+// sequential unfused sums (qjl.rs:44-57, 104-111, 180-182), so the stored rows are BIT-EXACT; the sign-weighted sum runs in index
+// order (qjl.rs:151-178 — the reference's host-SIMD variants, backend/cpu/simd.rs:1361-1374, differ from it by rounding).
+// kx: [kv head][max_seq][D / 32 + 1] words (bits, then the norm).  V rows: codes only — the reference computes QJL bits for V rows
+// too but never reads them (kv_turboquant.rs:154-170).
 // ------------------------------------------------------------------------------------------------
-template <int D, int G, int BITS>
+template <int D, int G, int BITS, bool QJL>
 __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __restrict__ q, uint8_t* __restrict__ kq, uint8_t* __restrict__ vq,
                                                               const float* __restrict__ k_new, const float* __restrict__ v_new,
                                                               const float* __restrict__ signs, const TqTables T, uint32_t max_seq, float scale,
                                                               const int* pos_ptr, uint32_t n_splits, uint32_t cap,
-                                                              float* __restrict__ part_ml, float* __restrict__ part_acc) {
+                                                              float* __restrict__ part_ml, float* __restrict__ part_acc,
+                                                              const float* __restrict__ qjl_s, uint32_t* __restrict__ kx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t RB = tq_row_bytes<BITS>(D);
-  float* rot = reinterpret_cast<float*>(smem);                       // [G + 2][D]
-  uint8_t* newk = smem + (G + 2) * D * 4;                            // [RB] (padded to 64)
+  constexpr uint32_t NROT = QJL ? 2 * G + 3 : G + 2;
+  constexpr uint32_t XW = D / 32 + 1;                                // words of a QJL row
+  float* rot = reinterpret_cast<float*>(smem);                       // [G + 2][D] (+ QJL: pq[G][D], res[D])
+  float* pq = rot + (G + 2) * D;
+  float* res = pq + G * D;
+  uint8_t* newk = smem + NROT * D * 4;                               // [RB] (padded to 64)
   uint8_t* newv = newk + 64;
-  float* sc = reinterpret_cast<float*>(newv + 64);                   // [G][cap]
+  uint32_t* newx = reinterpret_cast<uint32_t*>(newv + 64);           // [XW] (padded to 32 bytes)
+  float* sc = reinterpret_cast<float*>(newv + 64 + 32);              // [G][cap]
   float* redm = sc + (size_t)G * cap;                                // [G][8]  per-wave maxima / sums
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,6 +195,11 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
   uint8_t* krow0 = kq + (size_t)kvh * max_seq * RB;
   uint8_t* vrow0 = vq + (size_t)kvh * max_seq * RB;
   if (sp == 0 && tid < RB) { krow0[(size_t)pos * RB + tid] = newk[tid]; vrow0[(size_t)pos * RB + tid] = newv[tid]; }
+  uint32_t* xrow0 = QJL ? kx + (size_t)kvh * max_seq * XW : nullptr;
+  if (QJL) {
+    tq_qjl_rows<D, BITS>(T, qjl_s + (size_t)kvh * D * D, G, rot, rot + G * D, newk, res, pq, newx);
+    if (sp == 0 && tid < XW) xrow0[(size_t)pos * XW + tid] = newx[tid];
+  }
   // ---- scores: position p = (it * 256 + tid) * n_splits + sp; one lane walks the D coordinates of its position in order
   const uint32_t npos = kv_len > sp ? (kv_len - sp + n_splits - 1) / n_splits : 0;   // positions of this split
   float mloc[G];
@@ -170,9 +229,37 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
     }
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      s[g] *= scale;
+      if (!QJL) s[g] *= scale;
       sc[(size_t)g * cap + j] = s[g];
-      mloc[g] = fmaxf(mloc[g], s[g]);
+      if (!QJL) mloc[g] = fmaxf(mloc[g], s[g]);
+    }
+  }
+  if (QJL) {
+    // second pass over the split's positions: score = (polar_score + inner_product_fast) * scale (quant.rs:152-166, qjl.rs:120-131,
+    // kv_turboquant.rs:146-148).  (Its own loop: fused into the loop above the compiler keeps both query images in registers.)
+    for (uint32_t j = tid; j < npos; j += 256) {
+      const uint32_t p = j * n_splits + sp;
+      const uint32_t* xr = p == pos ? newx : xrow0 + (size_t)p * XW;
+      float t[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) t[g] = 0.0f;
+#pragma unroll
+      for (uint32_t w = 0; w < (uint32_t)D / 32; w++) {
+        uint32_t bits = xr[w];
+#pragma unroll 8
+        for (uint32_t b = 0; b < 32; b++, bits >>= 1) {
+          const bool plus = bits & 1u;
+#pragma unroll
+          for (int g = 0; g < G; g++) { const float v = pq[g * D + w * 32 + b]; t[g] += plus ? v : -v; }   // sum += values[i] * (+-1)
+        }
+      }
+      const float cn = T.qjl_coeff * __uint_as_float(xr[D / 32]);      // coeff * key_norm * sum, left to right
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const float sg = (sc[(size_t)g * cap + j] + cn * t[g]) * scale;
+        sc[(size_t)g * cap + j] = sg;
+        mloc[g] = fmaxf(mloc[g], sg);
+      }
     }
   }
   // ---- the split's softmax state per head: m = max, l = sum exp(s - m)
@@ -260,9 +347,11 @@ __global__ void __launch_bounds__(D) attn_tq_combine_kernel(const float* __restr
 // one row through the compressor (the code path of attn_tq_partial_kernel's new-row handling, stand-alone): lgh_op_tq_compress
 template <int D, int BITS>
 __global__ void __launch_bounds__(256) tq_compress_kernel(const float* __restrict__ x, const float* __restrict__ signs, const TqTables T,
-                                                          uint8_t* __restrict__ out) {
+                                                          uint8_t* __restrict__ out, const float* __restrict__ qjl_s, uint32_t* __restrict__ qjl_out) {
   __shared__ float rot[D];
-  __shared__ uint8_t code[64];
+  __shared__ float res[D];
+  __shared__ __attribute__((aligned(16))) uint8_t code[64];
+  __shared__ uint32_t newx[8];
   for (uint32_t i = threadIdx.x; i < D; i += 256) rot[i] = x[i] * signs[i];
   tq_fwht_rows<D>(rot, 1);
   for (uint32_t i = threadIdx.x; i < D; i += 256) rot[i] *= T.norm;
@@ -270,6 +359,10 @@ __global__ void __launch_bounds__(256) tq_compress_kernel(const float* __restric
   tq_pack_row<D, BITS>(T, rot, code);
   __syncthreads();
   if (threadIdx.x < tq_row_bytes<BITS>(D)) out[threadIdx.x] = code[threadIdx.x];
+  if (qjl_s) {   // TurboQuantEngine::compress with use_qjl (quant.rs:83-97): D / 32 words of sign bits, then the residual norm
+    tq_qjl_rows<D, BITS>(T, qjl_s, 0, nullptr, rot, code, res, nullptr, newx);
+    if (threadIdx.x < D / 32 + 1) qjl_out[threadIdx.x] = newx[threadIdx.x];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -288,6 +381,7 @@ static TqTables tq_tables(uint32_t d, int bits) {
   T.norm = 1.0f / std::sqrt((float)d);
   T.inv_scale = std::sqrt((float)d);
   T.inv_d = 1.0f / (float)d;
+  T.qjl_coeff = std::sqrt(1.57079632679489661923f) / (float)d;   // FRAC_PI_2.sqrt() / dim (qjl.rs:70, 128)
   return T;
 }
 
@@ -295,29 +389,37 @@ uint32_t tq_row_bytes_host(int bits, uint32_t d) { return bits == 2 ? d / 4 : d 
 // positions one split can hold scores for: max_seq spread over the splits
 uint32_t tq_split_cap(uint32_t max_seq, uint32_t n_splits) { return (max_seq + n_splits - 1) / n_splits; }
 
-template <int D, int G, int BITS>
-static hipError_t attn_tq_go(const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs, uint32_t n_kv,
-                             uint32_t max_seq, float scale, const int* pos, uint32_t n_splits, float* part_ml, float* part_acc, hipStream_t st) {
+struct TqArgs {
+  const float* q; uint8_t *kq, *vq; const float *k_new, *v_new, *signs; uint32_t n_kv, max_seq; float scale; const int* pos; uint32_t n_splits;
+  float *part_ml, *part_acc; const float* qjl_s; uint32_t* kx; hipStream_t st;
+};
+
+template <int D, int G, int BITS, bool QJL>
+static hipError_t attn_tq_go(const TqArgs& a) {
   static bool attr_set[64] = {};
-  const uint32_t cap = tq_split_cap(max_seq, n_splits);
-  const size_t lds = (size_t)(G + 2) * D * 4 + 128 + (size_t)G * cap * 4 + (size_t)G * 8 * 4 + 64;
+  const uint32_t cap = tq_split_cap(a.max_seq, a.n_splits);
+  const size_t lds = (size_t)(QJL ? 2 * G + 3 : G + 2) * D * 4 + 128 + 32 + (size_t)G * cap * 4 + (size_t)G * 8 * 4 + 64;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS>), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS>), dim3(n_kv * n_splits), dim3(256), lds, st, q, kq, vq, k_new, v_new, signs,
-                     tq_tables(D, BITS), max_seq, scale, pos, n_splits, cap, part_ml, part_acc);
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS, QJL>), 160 * 1024, attr_set); e != hipSuccess) return e;
+  hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS, QJL>), dim3(a.n_kv * a.n_splits), dim3(256), lds, a.st, a.q, a.kq, a.vq, a.k_new, a.v_new,
+                     a.signs, tq_tables(D, BITS), a.max_seq, a.scale, a.pos, a.n_splits, cap, a.part_ml, a.part_acc, a.qjl_s, a.kx);
   return hipGetLastError();
 }
 
-// bits 2 / 3; signs: this layer's [n_kv][2][head_dim]
+// bits 2 / 3; signs: this layer's [n_kv][2][head_dim]; qjl_s (TurboQuantProd; NULL = TurboQuantMSE): this layer's [n_kv][head_dim][head_dim],
+// kx: its QJL rows [n_kv][max_seq][head_dim / 32 + 1]
 hipError_t attn_tq_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs,
                           uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
-                          float* part_ml, float* part_acc, hipStream_t st) {
-  if (n_kv == 0 || n_heads % n_kv || !pos || (bits != 2 && bits != 3) || n_splits == 0 || n_splits > 32) return hipErrorInvalidValue;
+                          float* part_ml, float* part_acc, hipStream_t st, const float* qjl_s, uint32_t* kx) {
+  if (n_kv == 0 || n_heads % n_kv || !pos || (bits != 2 && bits != 3) || n_splits == 0 || n_splits > 32 || (qjl_s != nullptr) != (kx != nullptr))
+    return hipErrorInvalidValue;
   const uint32_t g = n_heads / n_kv;
-#define LGH_TQ_CASE(DD, GG)                                                                                                            \
-  if (head_dim == DD && g == GG)                                                                                                       \
-    return bits == 2 ? attn_tq_go<DD, GG, 2>(q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st) \
-                     : attn_tq_go<DD, GG, 3>(q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, st);
+  const TqArgs a{q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, qjl_s, kx, st};
+#define LGH_TQ_CASE(DD, GG)                                                                              \
+  if (head_dim == DD && g == GG) {                                                                       \
+    if (qjl_s) return bits == 2 ? attn_tq_go<DD, GG, 2, true>(a) : attn_tq_go<DD, GG, 3, true>(a);       \
+    return bits == 2 ? attn_tq_go<DD, GG, 2, false>(a) : attn_tq_go<DD, GG, 3, false>(a);                \
+  }
   LGH_TQ_CASE(128, 1) LGH_TQ_CASE(128, 2) LGH_TQ_CASE(128, 4) LGH_TQ_CASE(128, 8)
   LGH_TQ_CASE(64, 1) LGH_TQ_CASE(64, 2) LGH_TQ_CASE(64, 4) LGH_TQ_CASE(64, 8)
 #undef LGH_TQ_CASE
@@ -336,14 +438,15 @@ hipError_t attn_tq_combine_launch(int bits, const float* part_ml, const float* p
   return hipGetLastError();
 }
 
-// x[dim] -> codes[row bytes] with the given sign vector (dim 64 or 128)
-hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st) {
-  if ((bits != 2 && bits != 3) || (dim != 64 && dim != 128)) return hipErrorInvalidValue;
+// x[dim] -> codes[row bytes] with the given sign vector (dim 64 or 128); qjl_s[dim][dim] (optional) -> qjl_out[dim / 32 + 1] words
+hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st, const float* qjl_s,
+                              uint32_t* qjl_out) {
+  if ((bits != 2 && bits != 3) || (dim != 64 && dim != 128) || (qjl_s != nullptr) != (qjl_out != nullptr)) return hipErrorInvalidValue;
   const TqTables T = tq_tables(dim, bits);
-  if (dim == 128 && bits == 2) hipLaunchKernelGGL((tq_compress_kernel<128, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out);
-  else if (dim == 128) hipLaunchKernelGGL((tq_compress_kernel<128, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out);
-  else if (bits == 2) hipLaunchKernelGGL((tq_compress_kernel<64, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out);
-  else hipLaunchKernelGGL((tq_compress_kernel<64, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out);
+  if (dim == 128 && bits == 2) hipLaunchKernelGGL((tq_compress_kernel<128, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out, qjl_s, qjl_out);
+  else if (dim == 128) hipLaunchKernelGGL((tq_compress_kernel<128, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out, qjl_s, qjl_out);
+  else if (bits == 2) hipLaunchKernelGGL((tq_compress_kernel<64, 2>), dim3(1), dim3(256), 0, st, x, signs, T, out, qjl_s, qjl_out);
+  else hipLaunchKernelGGL((tq_compress_kernel<64, 3>), dim3(1), dim3(256), 0, st, x, signs, T, out, qjl_s, qjl_out);
   return hipGetLastError();
 }
 

@@ -243,10 +243,11 @@ hipError_t attn_q8_launch(int fmt, const float* q, int8_t* k8, int8_t* v8, float
 // decode attention over the TurboQuant code caches (attention_tq.hip); signs: the layer's [n_kv][2][head_dim]
 hipError_t attn_tq_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs,
                           uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
-                          float* part_ml, float* part_acc, hipStream_t st);
+                          float* part_ml, float* part_acc, hipStream_t st, const float* qjl_s = nullptr, uint32_t* kx = nullptr);
 hipError_t attn_tq_combine_launch(int bits, const float* part_ml, const float* part_acc, const float* signs, uint32_t n_heads, uint32_t n_kv,
                                   uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
-hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st);
+hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st, const float* qjl_s = nullptr,
+                              uint32_t* qjl_out = nullptr);
 uint32_t tq_row_bytes_host(int bits, uint32_t d);
 hipError_t attn_decode_any_launch(const float* q, const float* kcache, const float* vcache, float* out, uint32_t n_heads, uint32_t n_kv,
                                   uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, hipStream_t st);

@@ -21,6 +21,7 @@ struct LayerW {
   // LGH_FLAG_KV_INT8: int8 rows [kv_head][max_seq][head_dim] + one f32 scale per (kv_head, position) instead of the f32 caches
   int8_t *k8 = nullptr, *v8 = nullptr;
   float *kscale = nullptr, *vscale = nullptr;
+  uint32_t* kx = nullptr;   // TurboQuantProd: QJL rows of the K cache, [kv head][max_seq][head_dim / 32 + 1] words (sign bits, residual norm)
   bool moe() const { return router != nullptr; }
 };
 
@@ -104,6 +105,8 @@ struct lgh_ctx {
   lgh::BatchScratch batch;
   float* tq_signs = nullptr;                   // TurboQuant KV cache: [owned layer][kv head][k, v][head_dim] rotation signs (device)
   std::vector<float> tq_signs_host;
+  float* tq_qjl = nullptr;                     // TurboQuantProd: [owned layer][kv head][head_dim][head_dim] QJL projection matrices (device)
+  std::vector<float> tq_qjl_host;
   float* kv_shift_tmp = nullptr;               // scratch of lgh_kv_shift_left (one cache tensor), allocated at first use
 };
 

@@ -64,7 +64,9 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
 // otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
 // 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
 constexpr uint32_t kDirectAttnDefaultKv = 64;
-static inline bool kv_is_tq(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ3; }
+static inline bool kv_is_tq(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ3 || t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
+static inline bool kv_is_qjl(uint32_t t) { return t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
+static inline int kv_tq_bits(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ2_QJL ? 2 : 3; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,12 +560,15 @@ static int layer_forward(lgh_ctx* c, uint32_t li, const float* next_nw, bool nex
                             (d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4 : kv8 ? d.head_dim : d.head_dim * 4);
   if (kv_is_tq(d.kv_cache_type)) {
     // TurboQuantKVCache (kv_turboquant.rs): write_kv + attention_layer over the codes; the merge also inverts the V rotation
-    const int bits = d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3;
+    const int bits = kv_tq_bits(d.kv_cache_type);
     const float* signs = c->tq_signs + (size_t)(li - c->l0) * d.num_kv_heads * 2 * d.head_dim;
-    const uint64_t tq_bytes = (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * tq_row_bytes_host(bits, d.head_dim);
+    const bool qjl = kv_is_qjl(d.kv_cache_type);
+    const float* qjl_s = qjl ? c->tq_qjl + (size_t)(li - c->l0) * d.num_kv_heads * d.head_dim * d.head_dim : nullptr;
+    const uint64_t tq_bytes = (uint64_t)d.num_kv_heads * (c->pos + 1) * (2 * tq_row_bytes_host(bits, d.head_dim) + (qjl ? d.head_dim / 8 + 4 : 0)) +
+                              (qjl ? (uint64_t)d.num_kv_heads * d.head_dim * d.head_dim * 4 : 0);
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, tq_bytes, [&] {
            return attn_tq_launch(bits, c->q, (uint8_t*)Lw.k8, (uint8_t*)Lw.v8, k_new, v_new, signs, d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len,
-                                 scale, c->state + ST_POS, c->n_splits, c->part_ml, c->part_acc, c->stream);
+                                 scale, c->state + ST_POS, c->n_splits, c->part_ml, c->part_acc, c->stream, qjl_s, qjl ? Lw.kx : nullptr);
          })))
       return rc;
     XqBuf* qa = mfma_type(Lw.wo.type) ? xq_get(c, c->attn_out, d.num_heads * d.head_dim) : nullptr;
@@ -980,7 +985,7 @@ int lgh_create(const lgh_model_desc* desc, lgh_ctx** out) {
   lgh_model_desc d{};
   std::memcpy(&d, desc, desc->struct_size);
   d.struct_size = sizeof(lgh_model_desc);
-  if (d.kv_cache_type > LGH_KV_TQ3) return LGH_INVALID_ARGUMENT;
+  if (d.kv_cache_type > LGH_KV_TQ3_QJL) return LGH_INVALID_ARGUMENT;
   if (d.flags & LGH_FLAG_REMOVED_MASK) return LGH_UNSUPPORTED;   // the decode structures removed in round 3 (llama_gguf_hip.h)
   if (d.kv_cache_type == LGH_KV_F32 && (d.flags & LGH_FLAG_KV_INT8)) d.kv_cache_type = LGH_KV_INT8;
   // every byte-per-element cache shares the int8 cache's structure (staged f32 rows, the attention launch quantizes and stores
@@ -1032,6 +1037,20 @@ int lgh_set_kv_rotation_signs(lgh_ctx* c, const float* signs, size_t n) {
   for (size_t i = 0; i < n; i++)
     if (signs[i] != 1.0f && signs[i] != -1.0f) return fail(c, LGH_INVALID_ARGUMENT, "sign values must be +1 or -1");
   c->tq_signs_host.assign(signs, signs + n);
+  return LGH_OK;
+}
+
+// The QJL projection matrices of the K engines (TurboQuantProd; QjlProjector, src/model/turboquant/qjl.rs:21-62), before lgh_finalize:
+// [owned layer][kv head][head_dim][head_dim] in the order the reference draws them (row i, then column j).
+int lgh_set_kv_qjl_matrices(lgh_ctx* c, const float* m, size_t n) {
+  if (!c) return LGH_INVALID_ARGUMENT;
+  if (c->finalized) return fail(c, LGH_INVALID_ARGUMENT, "the QJL matrices must be given before lgh_finalize");
+  if (!kv_is_qjl(c->d.kv_cache_type)) return fail(c, LGH_INVALID_ARGUMENT, "this context has no TurboQuantProd (QJL) KV cache");
+  const size_t want = (size_t)(c->l1 - c->l0) * c->d.num_kv_heads * c->d.head_dim * c->d.head_dim;
+  if (!m || n != want) return fail(c, LGH_INVALID_ARGUMENT, "expected " + std::to_string(want) + " matrix elements");
+  for (size_t i = 0; i < n; i++)
+    if (!std::isfinite(m[i])) return fail(c, LGH_INVALID_ARGUMENT, "QJL matrix elements must be finite");
+  c->tq_qjl_host.assign(m, m + n);
   return LGH_OK;
 }
 
@@ -1179,12 +1198,18 @@ int lgh_finalize(lgh_ctx* c) {
       // QuantizedKVCache::new with KVCacheFormat::Int8 (kv_quantized.rs:57-102): int8 rows + a scale per (kv head, position)
       const size_t n_rows = (size_t)d.num_kv_heads * d.max_seq_len;
       if (kv_is_tq(d.kv_cache_type)) {   // TurboQuantKVCache::new (kv_turboquant.rs:36-86): packed codes, no scales, no norms
-        const size_t bytes = n_rows * tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim);
+        const size_t bytes = n_rows * tq_row_bytes_host(kv_tq_bits(d.kv_cache_type), d.head_dim);
         for (int8_t** p8 : {&L.k8, &L.v8}) {
           if ((rc = dev_alloc(c, (void**)p8, bytes))) return rc;
           HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(*p8, 0, bytes, c->stream));
         }
         c->stats.kv_bytes += 2 * bytes;
+        if (kv_is_qjl(d.kv_cache_type)) {   // + per K row: sign bits of the projected residual and its norm (quant.rs:176-186)
+          const size_t xb = n_rows * (d.head_dim / 32 + 1) * 4;
+          if ((rc = dev_alloc(c, (void**)&L.kx, xb))) return rc;
+          HIP_TRY(c, LGH_OPERATION_FAILED, hipMemsetAsync(L.kx, 0, xb, c->stream));
+          c->stats.kv_bytes += xb;
+        }
         continue;
       }
       for (int8_t** p8 : {&L.k8, &L.v8}) {
@@ -1250,6 +1275,26 @@ int lgh_finalize(lgh_ctx* c) {
     if (c->tq_signs_host.size() != n) return fail(c, LGH_INVALID_ARGUMENT, "the rotation sign vector has the wrong length for this context");
     if ((rc = dev_alloc(c, (void**)&c->tq_signs, n * 4))) return rc;
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(c->tq_signs, c->tq_signs_host.data(), n * 4, hipMemcpyHostToDevice));
+    if (kv_is_qjl(d.kv_cache_type)) {
+      // the K engines' projection matrices, [owned layer][kv head][head_dim][head_dim]: given through lgh_set_kv_qjl_matrices, otherwise
+      // a deterministic stand-in (Box-Muller over a counter hash: i.i.d. N(0, 1), NOT the reference's StdRng / ziggurat stream)
+      const size_t nm = (size_t)(c->l1 - c->l0) * d.num_kv_heads * d.head_dim * d.head_dim;
+      if (c->tq_qjl_host.empty()) {
+        c->tq_qjl_host.resize(nm);
+        auto mix = [](uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; };
+        const uint64_t base = (uint64_t)c->l0 * d.num_kv_heads * d.head_dim * d.head_dim;
+        for (size_t i = 0; i < nm; i += 2) {
+          const uint64_t a = mix((base + i) * 0x9E3779B97F4A7C15ull + 0x51ED270B7F4A7C15ull), b = mix(a + 0xD1B54A32D192ED03ull);
+          const double u1 = ((double)(a >> 11) + 1.0) * (1.0 / 9007199254740993.0), u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+          const double r = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586 * u2;
+          c->tq_qjl_host[i] = (float)(r * std::cos(th));
+          if (i + 1 < nm) c->tq_qjl_host[i + 1] = (float)(r * std::sin(th));
+        }
+      }
+      if (c->tq_qjl_host.size() != nm) return fail(c, LGH_INVALID_ARGUMENT, "the QJL matrices have the wrong size for this context");
+      if ((rc = dev_alloc(c, (void**)&c->tq_qjl, nm * 4))) return rc;
+      HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpy(c->tq_qjl, c->tq_qjl_host.data(), nm * 4, hipMemcpyHostToDevice));
+    }
   }
   // XQ images of the vectors that feed quantized mat-vecs (allocated here, never during a graph capture)
   if (!xq_get(c, c->hidden, d.hidden_size) || !xq_get(c, c->attn_out, d.num_heads * d.head_dim) || !xq_get(c, c->act, (uint32_t)ffn) ||
@@ -1443,8 +1488,9 @@ int lgh_kv_shift_left(lgh_ctx* c, size_t amount) {
     for (uint32_t li = c->l0; li < c->l1; li++) {
       LayerW& L = c->layers[li];
       if (kv_is_tq(d.kv_cache_type)) {   // TurboQuantKVCache::shift_left (kv_turboquant.rs:245-266): code rows
-        const size_t rb = tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim);
+        const size_t rb = tq_row_bytes_host(kv_tq_bits(d.kv_cache_type), d.head_dim);
         if ((rc = shift(L.k8, rb)) || (rc = shift(L.v8, rb))) return rc;
+        if (kv_is_qjl(d.kv_cache_type) && (rc = shift(L.kx, (size_t)(d.head_dim / 32 + 1) * 4))) return rc;
       } else if (d.flags & LGH_FLAG_KV_INT8) {
         if ((rc = shift(L.k8, d.head_dim)) || (rc = shift(L.v8, d.head_dim))) return rc;
         if (d.kv_cache_type == LGH_KV_INT8 && ((rc = shift(L.kscale, 4)) || (rc = shift(L.vscale, 4)))) return rc;
@@ -1504,7 +1550,7 @@ int lgh_get_stats(lgh_ctx* c, lgh_stats* out) {
       if (L.moe()) b += (uint64_t)d.num_experts_per_token * (L.gate_exps.bytes + L.up_exps.bytes + L.down_exps.bytes) + (uint64_t)d.num_experts * d.hidden_size * 4;
       else b += L.gate.bytes + L.up.bytes + L.down.bytes;
       b += (uint64_t)2 * d.hidden_size * 4;                                       // norm weights
-      const uint64_t kv_row = kv_is_tq(d.kv_cache_type) ? tq_row_bytes_host(d.kv_cache_type == LGH_KV_TQ2 ? 2 : 3, d.head_dim)
+      const uint64_t kv_row = kv_is_tq(d.kv_cache_type) ? tq_row_bytes_host(kv_tq_bits(d.kv_cache_type), d.head_dim)
                               : d.kv_cache_type == LGH_KV_INT8 ? d.head_dim + 4                                // int8 row + its scale
                               : d.kv_cache_type != LGH_KV_F32 ? d.head_dim : (uint64_t)d.head_dim * 4;
       b += (uint64_t)2 * d.num_kv_heads * (c->pos + 1) * kv_row;                  // KV read (kv_len = pos+1)

@@ -115,12 +115,21 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb_kernel(uint32_t wbpack, uin
 #pragma unroll
     for (int s = 0; s < NB; s++) {
       if ((uint32_t)s < n_seq) {
+#ifdef LGH_MVQB_NOMAC   // experiment: memory side only
+        acc[s][0] += xr[s % kXd].xs[0] + __builtin_bit_cast(float, xr[s % kXd].a[3][3]) + t0.dd;
+        acc[s][1] += xr[s % kXd].sx[1] + t1.dd;
+#else
         mvq_mac_tile<MASK>(fmt, t0, xr[s % kXd], acc[s][0]);
         if (two) mvq_mac_tile<MASK>(fmt, t1, xr[s % kXd], acc[s][1]);
+#endif
+#ifndef LGH_MVQB_NOX    // experiment: arithmetic side only
         if ((uint32_t)(s + kXd) < n_seq) x_issue(b, s + kXd, xr[s % kXd]);
+#endif
       }
     }
+#ifndef LGH_MVQB_NOX
     if (more) x_prime(b_next);   // the next step's first sequences, ahead of its weight prefetch
+#endif
     if (b + 1 == nblk_w) {   // last block of the group's pairs: the four lane groups -> one partial sum per row and sequence
 #pragma unroll
       for (int s = 0; s < NB; s++) {

@@ -296,6 +296,32 @@ int lgh_op_tq_compress(int device, int bits, const float* x, size_t dim, const f
   return LGH_OK;
 }
 
+int lgh_op_tq_compress_qjl(int device, int bits, const float* x, size_t dim, const float* signs, const float* qjl_matrix, uint8_t* codes,
+                           uint64_t* qjl_bits, float* residual_norm) {
+  Tmp t(device);
+  if (t.rc) return t.rc;
+  if (!x || !signs || !codes || !qjl_matrix || !qjl_bits || !residual_norm) return LGH_INVALID_ARGUMENT;
+  if ((bits != 2 && bits != 3) || (dim != 64 && dim != 128)) return LGH_UNSUPPORTED;
+  for (size_t i = 0; i < dim; i++)
+    if (signs[i] != 1.0f && signs[i] != -1.0f) return LGH_INVALID_ARGUMENT;
+  float *dx = t.up(x, dim), *ds = t.up(signs, dim), *dS = t.up(qjl_matrix, dim * dim);
+  const size_t rb = tq_row_bytes_host(bits, (uint32_t)dim), xw = dim / 32 + 1;
+  uint8_t* dc = reinterpret_cast<uint8_t*>(t.up(nullptr, (rb + 3) / 4));
+  uint32_t* dq = reinterpret_cast<uint32_t*>(t.up(nullptr, xw));
+  if (!dx || !ds || !dS || !dc || !dq) return LGH_ALLOCATION_FAILED;
+  if (tq_compress_launch(bits, dx, (uint32_t)dim, ds, dc, t.c->stream, dS, dq) != hipSuccess) return LGH_OPERATION_FAILED;
+  std::vector<float> tmp((rb + 3) / 4), tq(xw);
+  int rc = t.down(tmp.data(), reinterpret_cast<float*>(dc), (rb + 3) / 4);
+  if (rc) return rc;
+  if ((rc = t.down(tq.data(), reinterpret_cast<float*>(dq), xw))) return rc;
+  std::memcpy(codes, tmp.data(), rb);
+  uint32_t w[8] = {};
+  std::memcpy(w, tq.data(), xw * 4);
+  for (size_t i = 0; i < dim / 64; i++) qjl_bits[i] = (uint64_t)w[2 * i] | (uint64_t)w[2 * i + 1] << 32;
+  std::memcpy(residual_norm, &w[dim / 32], 4);
+  return LGH_OK;
+}
+
 int lgh_op_matmul(int device, const float* a, const float* b, float* out, size_t m, size_t k, size_t n) {
   Tmp t(device);
   if (t.rc) return t.rc;

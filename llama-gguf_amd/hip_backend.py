@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "lgh_pipeline_create", "lgh_pipeline_upload_tensor", "lgh_pipeline_finalize", "lgh_pipeline_destroy", "lgh_pipeline_forward",
     "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_stages",
     "lgh_pipeline_last_error",
-    "lgh_set_kv_rotation_signs", "lgh_op_tq_compress",
+    "lgh_set_kv_rotation_signs", "lgh_op_tq_compress", "lgh_set_kv_qjl_matrices", "lgh_op_tq_compress_qjl",
     "lgh_batch_create", "lgh_batch_reset", "lgh_batch_position", "lgh_batch_prefill", "lgh_forward_multi", "lgh_decode_greedy_multi",
 )
 
@@ -52,6 +52,7 @@ FLAG_NO_GRAPH = 1
 FLAG_EXACT_PREFILL = 4   # forward_batch feeds tokens one by one (f32 throughout) instead of the batched f16 GEMM path
 KV_F32, KV_INT8, KV_FP8_E4M3, KV_FP8_E5M2 = 0, 1, 2, 3   # lgh_model_desc.kv_cache_type: f32, or QuantizedKVCache's formats (kv_quantized.rs; no CLI flag reaches them)
 KV_TQ2, KV_TQ3 = 4, 5   # KVCacheType::TurboQuantMSE { bits: 2 | 3 }: what `--kv-cache-type tq2 | tq3` selects (src/config.rs:808-817)
+KV_TQ2_QJL, KV_TQ3_QJL = 6, 7   # KVCacheType::TurboQuantProd { bits: 2 | 3 }: `tq2-qjl | tq3-qjl`
 FLAG_KV_INT8 = 16   # KV cache in the reference's int8 format (kv_quantized.rs: int8 rows + one scale per head and position)
 FLAG_REMOVED_MASK = 2 | 8 | 32 | 64 | 128 | (0xFF << 24)   # round-2 decode experiments, removed in round 3: lgh_create answers Unsupported
 
@@ -160,6 +161,7 @@ def load_library() -> C.CDLL:
         "lgh_pipeline_decode_greedy": (C.c_int, [vp, u32, sz, vp]), "lgh_pipeline_reset": (None, [vp]),
         "lgh_pipeline_position": (sz, [vp]), "lgh_pipeline_stages": (C.c_int, [vp]), "lgh_pipeline_last_error": (C.c_char_p, [vp]),
         "lgh_set_kv_rotation_signs": (C.c_int, [vp, vp, sz]), "lgh_op_tq_compress": (C.c_int, [C.c_int, C.c_int, vp, sz, vp, vp]),
+        "lgh_set_kv_qjl_matrices": (C.c_int, [vp, vp, sz]), "lgh_op_tq_compress_qjl": (C.c_int, [C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp]),
         "lgh_batch_create": (C.c_int, [vp, u32]), "lgh_batch_reset": (C.c_int, [vp, u32]), "lgh_batch_position": (sz, [vp, u32]),
         "lgh_batch_prefill": (C.c_int, [vp, u32, vp, sz]), "lgh_forward_multi": (C.c_int, [vp, vp, vp, u32, vp, vp]),
         "lgh_decode_greedy_multi": (C.c_int, [vp, vp, vp, u32, sz, vp]),
@@ -196,7 +198,7 @@ class HipGpuInference:
     @classmethod
     def from_model(cls, model, max_seq_len: int, device: int = 0, layer_range: Optional[Sequence[int]] = None,
                    flags: int = 0, attn_splits: int = 0, attn_direct: int = 0, kv_cache_type: int = 0,
-                   kv_rotation_signs=None) -> "HipGpuInference":
+                   kv_rotation_signs=None, kv_qjl_matrices=None) -> "HipGpuInference":
         """`model` hands over what LlamaModel::into_parts does (llama.rs:138-160): `.config` and
         `.tensors(layers)` yielding (gguf_name, ggml_type, ne, host bytes)."""
         L = load_library()
@@ -222,6 +224,9 @@ class HipGpuInference:
             if kv_rotation_signs is not None:      # TurboQuant: HadamardRotation::signs() of every (layer, kv head, k / v) engine
                 sg = np.ascontiguousarray(kv_rotation_signs, dtype=np.float32)
                 self._call(L.lgh_set_kv_rotation_signs(self._h, sg.ctypes.data, sg.size))
+            if kv_qjl_matrices is not None:        # TurboQuantProd: the K engines' QjlProjector matrices [layer][kv head][d][d]
+                qm = np.ascontiguousarray(kv_qjl_matrices, dtype=np.float32)
+                self._call(L.lgh_set_kv_qjl_matrices(self._h, qm.ctypes.data, qm.size))
             for name, t, ne, data in model.tensors(range(lb, le)):
                 self.upload_tensor(name, t, ne, data)
             self._call(L.lgh_finalize(self._h))
@@ -604,6 +609,18 @@ def op_tq_compress(x, bits: int, signs, device: int = 0) -> np.ndarray:
     out = np.zeros(x.size // 4 if bits == 2 else x.size // 8 * 3, dtype=np.uint8)
     _chk(load_library().lgh_op_tq_compress(device, bits, x.ctypes.data, x.size, sg.ctypes.data, out.ctypes.data), "tq_compress")
     return out
+
+
+def op_tq_compress_qjl(x, bits: int, signs, qjl_matrix, device: int = 0):
+    """TurboQuantEngine::compress with use_qjl (quant.rs:71-103) on the device -> (codes, qjl_bits uint64[dim / 64], residual_norm)."""
+    x, sg, S = _f32(x), _f32(signs), _f32(qjl_matrix)
+    assert S.size == x.size * x.size
+    codes = np.zeros(x.size // 4 if bits == 2 else x.size // 8 * 3, dtype=np.uint8)
+    qb = np.zeros(x.size // 64, dtype=np.uint64)
+    norm = C.c_float(0.0)
+    _chk(load_library().lgh_op_tq_compress_qjl(device, bits, x.ctypes.data, x.size, sg.ctypes.data, S.ctypes.data, codes.ctypes.data,
+                                               qb.ctypes.data, C.addressof(norm)), "tq_compress_qjl")
+    return codes, qb, float(norm.value)
 
 
 def op_silu_mul(gate, up, device: int = 0) -> np.ndarray:

@@ -70,6 +70,10 @@ struct orc_model {
   int kv_tq_bits = 0;                                 // 2 / 3: KVCacheType::TurboQuantMSE { bits } (model/mod.rs:182-213)
   std::vector<float> tq_signs;                        // [layer][kv head][k, v][padded_dim]: HadamardRotation::signs() of every engine
   std::vector<std::vector<uint8_t>> tq_k, tq_v;       // per layer [kv head][max_seq][packed bytes]
+  // KVCacheType::TurboQuantProd { bits }: + the K engines' QJL projectors (qjl.rs) and, per cached K row, sign bits + residual norm
+  std::vector<float> tq_qjl;                          // [layer][kv head][padded_dim][padded_dim]; empty = TurboQuantMSE
+  std::vector<std::vector<uint64_t>> tq_kbits;        // per layer [kv head][max_seq][(padded_dim + 63) / 64]
+  std::vector<std::vector<float>> tq_knorm;           // per layer [kv head][max_seq]
   std::vector<float> last_hidden;
   size_t position = 0;
   bool finalized = false;
@@ -144,17 +148,28 @@ int attention_forward(orc_model* m, size_t li, const float* x, size_t pos, float
     uint8_t* kq = m->tq_k[li].data();
     uint8_t* vq = m->tq_v[li].data();
     auto signs = [&](size_t h, int kv) { return m->tq_signs.data() + ((li * nkv + h) * 2 + (size_t)kv) * pd; };
+    const bool qjl = !m->tq_qjl.empty();
+    const size_t nw = (pd + 63) / 64;
+    auto S = [&](size_t h) { return m->tq_qjl.data() + (li * nkv + h) * pd * pd; };
     for (size_t h = 0; h < nkv; h++) {
-      orc_tq_compress(k.data() + h * d, d, bits, signs(h, 0), kq + (h * ms + pos) * pb);
-      orc_tq_compress(v.data() + h * d, d, bits, signs(h, 1), vq + (h * ms + pos) * pb);
+      if (qjl)
+        orc_tq_compress_qjl(k.data() + h * d, d, bits, signs(h, 0), S(h), kq + (h * ms + pos) * pb, m->tq_kbits[li].data() + (h * ms + pos) * nw,
+                            m->tq_knorm[li].data() + h * ms + pos);
+      else
+        orc_tq_compress(k.data() + h * d, d, bits, signs(h, 0), kq + (h * ms + pos) * pb);
+      orc_tq_compress(v.data() + h * d, d, bits, signs(h, 1), vq + (h * ms + pos) * pb);   // (V's own QJL bits are never read)
     }
     std::vector<float> attn_tq(nh * d);
     const float scale_tq = 1.0f / std::sqrt((float)d);  // layers.rs:374
     const size_t per = nh / nkv;
     for (size_t h = 0; h < nh; h++) {
       const size_t kvh = h / per;
-      orc_tq_attention_head(q.data() + h * d, kq + kvh * ms * pb, vq + kvh * ms * pb, pos + 1, d, bits, signs(kvh, 0), signs(kvh, 1), scale_tq,
-                            attn_tq.data() + h * d);
+      if (qjl)
+        orc_tq_attention_head_qjl(q.data() + h * d, kq + kvh * ms * pb, m->tq_kbits[li].data() + kvh * ms * nw, m->tq_knorm[li].data() + kvh * ms,
+                                  vq + kvh * ms * pb, pos + 1, d, bits, signs(kvh, 0), signs(kvh, 1), S(kvh), scale_tq, attn_tq.data() + h * d);
+      else
+        orc_tq_attention_head(q.data() + h * d, kq + kvh * ms * pb, vq + kvh * ms * pb, pos + 1, d, bits, signs(kvh, 0), signs(kvh, 1), scale_tq,
+                              attn_tq.data() + h * d);
     }
     return linear_forward(m, L.wo, attn_tq.data(), out);
   }
@@ -360,6 +375,20 @@ int orc_model_set_kv_turboquant(orc_model* m, int bits, const float* signs, size
   const size_t pb = orc_tq_packed_bytes(bits, pd);
   m->tq_k.assign(c.num_layers, std::vector<uint8_t>((size_t)c.num_kv_heads * c.max_seq_len * pb));
   m->tq_v = m->tq_k;
+  m->tq_qjl.clear();
+  return 0;
+}
+
+// KVCacheType::TurboQuantProd { bits }: after orc_model_set_kv_turboquant(bits, signs), the K engines' QJL projection matrices
+// [layers][kv heads][padded_dim][padded_dim] (what QjlProjector draws from seed 4 base + 1, kv_turboquant.rs:55-58); NULL / 0 = none
+int orc_model_set_kv_turboquant_qjl(orc_model* m, const float* qjl, size_t n_qjl) {
+  if (!qjl || n_qjl == 0) { m->tq_qjl.clear(); return 0; }
+  const orc_config& c = m->cfg;
+  const size_t pd = orc_tq_padded_dim(c.head_dim);
+  if (!m->kv_tq_bits || n_qjl != (size_t)c.num_layers * c.num_kv_heads * pd * pd) return 1;
+  m->tq_qjl.assign(qjl, qjl + n_qjl);
+  m->tq_kbits.assign(c.num_layers, std::vector<uint64_t>((size_t)c.num_kv_heads * c.max_seq_len * ((pd + 63) / 64)));
+  m->tq_knorm.assign(c.num_layers, std::vector<float>((size_t)c.num_kv_heads * c.max_seq_len));
   return 0;
 }
 
@@ -464,6 +493,16 @@ void orc_model_kv_shift_left(orc_model* m, size_t amount) {  // KVCache::shift_l
     for (size_t li = 0; li < m->tq_k.size(); li++)
       for (auto* cache : {&m->tq_k[li], &m->tq_v[li]})
         for (size_t h = 0; h < c.num_kv_heads; h++) std::memmove(cache->data() + h * rs, cache->data() + h * rs + amount * pb, new_len * pb);
+    if (!m->tq_qjl.empty()) {
+      const size_t nw = (orc_tq_padded_dim(c.head_dim) + 63) / 64;
+      for (size_t li = 0; li < m->tq_kbits.size(); li++)
+        for (size_t h = 0; h < c.num_kv_heads; h++) {
+          uint64_t* b = m->tq_kbits[li].data() + h * c.max_seq_len * nw;
+          std::memmove(b, b + amount * nw, new_len * nw * 8);
+          float* nn = m->tq_knorm[li].data() + h * c.max_seq_len;
+          std::memmove(nn, nn + amount, new_len * 4);
+        }
+    }
   }
   m->position = new_len;   // the rows keep the RoPE rotation of their OLD positions (the reference does not re-rotate)
 }

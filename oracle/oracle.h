@@ -150,6 +150,19 @@ void orc_tq_compress(const float* x, size_t dim, int bits, const float* signs, u
 void orc_tq_attention_head(const float* query, const uint8_t* k_codes, const uint8_t* v_codes, size_t kv_len, size_t dim, int bits,
                            const float* signs_k, const float* signs_v, float scale, float* out);
 int orc_model_set_kv_turboquant(orc_model* m, int bits, const float* signs, size_t n_signs);
+/* TurboQuantProd (`tq2-qjl | tq3-qjl`, src/model/turboquant/qjl.rs): the projector's Gaussian matrix S[dim][dim] is an input */
+float orc_tq_dot_with_sign_bits(const float* values, const uint64_t* bits, size_t count);
+void orc_tq_qjl_project(const float* S, size_t dim, const float* q, float* out);
+void orc_tq_qjl_compress(const float* S, size_t dim, const float* x, uint64_t* bits, float* norm);
+float orc_tq_qjl_inner_product_fast(size_t dim, const float* projected_query, const uint64_t* bits, float key_norm);
+size_t orc_tq_bytes_per_entry(size_t dim, int bits, int use_qjl);
+void orc_tq_compress_qjl(const float* x, size_t dim, int bits, const float* signs, const float* S, uint8_t* packed, uint64_t* qjl_bits,
+                         float* residual_norm);
+void orc_tq_attention_head_qjl(const float* query, const uint8_t* k_codes, const uint64_t* k_qjl, const float* k_norm, const uint8_t* v_codes,
+                               size_t kv_len, size_t dim, int bits, const float* signs_k, const float* signs_v, const float* S_k, float scale,
+                               float* out);
+/* ... on a model: qjl = [layer][kv head][padded_dim][padded_dim], the K engines' matrices (NULL / 0: TurboQuantMSE) */
+int orc_model_set_kv_turboquant_qjl(orc_model* m, const float* qjl, size_t n_qjl);
 /* debug taps: hidden state after the last forward's final layer (pre-norm) */
 int orc_model_last_hidden(const orc_model* m, float* out);
 

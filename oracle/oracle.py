@@ -83,6 +83,12 @@ def lib() -> C.CDLL:
         "orc_tq_compress": (None, [vp, sz, C.c_int, vp, vp]),
         "orc_tq_attention_head": (None, [vp, vp, vp, sz, sz, C.c_int, vp, vp, C.c_float, vp]),
         "orc_model_set_kv_turboquant": (C.c_int, [vp, C.c_int, vp, sz]),
+        "orc_tq_dot_with_sign_bits": (C.c_float, [vp, vp, sz]), "orc_tq_qjl_project": (None, [vp, sz, vp, vp]),
+        "orc_tq_qjl_compress": (None, [vp, sz, vp, vp, vp]), "orc_tq_qjl_inner_product_fast": (C.c_float, [sz, vp, vp, C.c_float]),
+        "orc_tq_bytes_per_entry": (sz, [sz, C.c_int, C.c_int]),
+        "orc_tq_compress_qjl": (None, [vp, sz, C.c_int, vp, vp, vp, vp, vp]),
+        "orc_tq_attention_head_qjl": (None, [vp, vp, vp, vp, vp, sz, sz, C.c_int, vp, vp, vp, C.c_float, vp]),
+        "orc_model_set_kv_turboquant_qjl": (C.c_int, [vp, vp, sz]),
         "orc_argmax_last": (C.c_uint32, [vp, sz]), "orc_greedy_sample": (C.c_uint32, [vp, sz]),
         "orc_moe_route": (None, [vp, vp, sz, sz, sz, C.c_int, vp, vp]),
         "orc_model_create": (vp, [C.POINTER(Config)]), "orc_model_destroy": (None, [vp]),
@@ -358,6 +364,58 @@ def tq_compress(x, bits: int, signs) -> np.ndarray:
     return out
 
 
+def tq_dot_with_sign_bits(values, bits, count: int) -> float:
+    values, bits = _f32(values), np.ascontiguousarray(bits, dtype=np.uint64)
+    return float(lib().orc_tq_dot_with_sign_bits(_p(values), _p(bits), count))
+
+
+def tq_qjl_project(S, q) -> np.ndarray:
+    S, q = _f32(S), _f32(q)
+    out = np.zeros(q.size, np.float32)
+    lib().orc_tq_qjl_project(_p(S), q.size, _p(q), _p(out))
+    return out
+
+
+def tq_qjl_compress(S, x):
+    """-> (bits uint64[(dim + 63) // 64], norm)"""
+    S, x = _f32(S), _f32(x)
+    bits = np.zeros((x.size + 63) // 64, np.uint64)
+    norm = C.c_float(0.0)
+    lib().orc_tq_qjl_compress(_p(S), x.size, _p(x), _p(bits), C.byref(norm))
+    return bits, float(norm.value)
+
+
+def tq_qjl_inner_product_fast(projected_query, bits, norm: float) -> float:
+    pq, bits = _f32(projected_query), np.ascontiguousarray(bits, dtype=np.uint64)
+    return float(lib().orc_tq_qjl_inner_product_fast(pq.size, _p(pq), _p(bits), C.c_float(norm)))
+
+
+def tq_bytes_per_entry(dim: int, bits: int, use_qjl: bool) -> int:
+    return int(lib().orc_tq_bytes_per_entry(dim, bits, int(use_qjl)))
+
+
+def tq_compress_qjl(x, bits: int, signs, S):
+    """TurboQuantEngine::compress with QJL -> (codes uint8[], qjl_bits uint64[], residual_norm)"""
+    x, signs, S = _f32(x), _f32(signs), _f32(S)
+    pd = tq_padded_dim(x.size)
+    codes = np.zeros(tq_packed_bytes(bits, pd), np.uint8)
+    qb = np.zeros((pd + 63) // 64, np.uint64)
+    norm = C.c_float(0.0)
+    lib().orc_tq_compress_qjl(_p(x), x.size, bits, _p(signs), _p(S), _p(codes), _p(qb), C.byref(norm))
+    return codes, qb, float(norm.value)
+
+
+def tq_attention_head_qjl(query, k_codes, k_qjl, k_norm, v_codes, kv_len: int, bits: int, signs_k, signs_v, S_k, scale: float) -> np.ndarray:
+    query = _f32(query)
+    k_codes, v_codes = np.ascontiguousarray(k_codes, dtype=np.uint8), np.ascontiguousarray(v_codes, dtype=np.uint8)
+    k_qjl, k_norm = np.ascontiguousarray(k_qjl, dtype=np.uint64), _f32(k_norm)
+    signs_k, signs_v, S_k = _f32(signs_k), _f32(signs_v), _f32(S_k)
+    out = np.zeros(query.size, np.float32)
+    lib().orc_tq_attention_head_qjl(_p(query), _p(k_codes), _p(k_qjl), _p(k_norm), _p(v_codes), kv_len, query.size, bits, _p(signs_k), _p(signs_v),
+                                    _p(S_k), C.c_float(scale), _p(out))
+    return out
+
+
 def tq_attention_head(query, k_codes, v_codes, kv_len: int, bits: int, signs_k, signs_v, scale: float) -> np.ndarray:
     query = _f32(query)
     k_codes, v_codes = np.ascontiguousarray(k_codes, dtype=np.uint8), np.ascontiguousarray(v_codes, dtype=np.uint8)
@@ -415,6 +473,14 @@ class Model:
         self._keep.append(signs)
         if lib().orc_model_set_kv_turboquant(self._h, int(bits), _p(signs), signs.size):
             raise ValueError("orc_model_set_kv_turboquant: bad bits / sign vector")
+
+    def set_kv_turboquant_qjl(self, qjl) -> None:
+        """KVCacheType::TurboQuantProd { bits } on top of set_kv_turboquant: `qjl` = [layers][kv heads][pd][pd], the K engines'
+        QJL projection matrices (qjl.rs)."""
+        qjl = _f32(qjl)
+        self._keep.append(qjl)
+        if lib().orc_model_set_kv_turboquant_qjl(self._h, _p(qjl), qjl.size):
+            raise ValueError("orc_model_set_kv_turboquant_qjl: call set_kv_turboquant first / wrong matrix size")
 
     def set_kv_fp8(self, fmt: int) -> None:
         """K/V rows go through one of the reference's FP8 KV formats (FP8_E4M3 / FP8_E5M2; 0 = off)."""

@@ -9,11 +9,18 @@
 //   cache      src/model/kv_turboquant.rs:88-201         write_kv, attention_head (softmax_inplace quant.rs:228-242, the
 //                                                        weight < 1e-8 skip, one inverse rotation PER POSITION), attention_layer
 //
+//   qjl        src/model/turboquant/qjl.rs:21-178       TurboQuantProd (`tq2-qjl | tq3-qjl`): sign bits of S r for the residual r of
+//                                                        the scalar quantizer + its norm; asymmetric inner-product estimator
+//
 // The random sign vector of a rotation is an INPUT here (HadamardRotation::signs(), rotation.rs:126-129, exists for exactly that:
-// "useful for CUDA upload"): the reference draws it from rand's StdRng, which is not restated.  The QJL residual correction
-// (TurboQuantProd, qjl.rs) is not restated either — parity for tq2-qjl / tq3-qjl is not claimed anywhere.
+// "useful for CUDA upload"): the reference draws it from rand's StdRng, which is not restated.  The same holds for the QJL
+// projector's Gaussian matrix S (qjl.rs regenerates it row by row from StdRng + rand_distr::StandardNormal on every call): it is
+// an INPUT, [dim][dim] f32 in the order the reference draws it (row i = the i-th projection, column j).  The reference sums the
+// estimator's sign-weighted dot product with whatever SIMD width the host has (backend/cpu/simd.rs:1361-1374: AVX2 8 lanes, NEON,
+// or the scalar loop of qjl.rs:151-178); this restatement is the scalar loop.
 // Pinned by the reference's own unit tests of these files (tests/test_oracle_kat.py: codebook.rs:274-348, rotation.rs:137-229
-// — the ones that do not depend on the RNG stream — kv_turboquant.rs:289-428); everything else rests on the restatement.
+// — the ones that do not depend on the RNG stream — kv_turboquant.rs:289-428, qjl.rs:230-250, simd.rs:1302-1350, quant.rs:340-352);
+// everything else rests on the restatement.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -168,6 +175,96 @@ void orc_tq_attention_head(const float* query, const uint8_t* k_codes, const uin
   for (size_t p = 0; p < kv_len; p++) scores[p] = orc_tq_dot_with_packed(pd, bits, rot_q.data(), k_codes + p * pb, pd);
   for (size_t p = 0; p < kv_len; p++) scores[p] *= scale;
   if (kv_len) {                                                                          // softmax_inplace (quant.rs:228-242)
+    float mx = -INFINITY;
+    for (size_t p = 0; p < kv_len; p++) mx = std::fmax(mx, scores[p]);
+    float sum = 0.0f;
+    for (size_t p = 0; p < kv_len; p++) { scores[p] = std::exp(scores[p] - mx); sum += scores[p]; }
+    const float inv = 1.0f / sum;
+    for (size_t p = 0; p < kv_len; p++) scores[p] *= inv;
+  }
+  for (size_t i = 0; i < dim; i++) out[i] = 0.0f;
+  std::vector<float> deq(pd), orig(dim);
+  for (size_t p = 0; p < kv_len; p++) {
+    const float w = scores[p];
+    if (w < 1e-8f) continue;
+    orc_tq_dequantize_vector(pd, bits, v_codes + p * pb, pd, deq.data());
+    orc_tq_rotate_inverse(deq.data(), dim, signs_v, orig.data());
+    for (size_t i = 0; i < dim; i++) out[i] += w * orig[i];
+  }
+}
+
+// ---- QJL (TurboQuantProd) ----------------------------------------------------------------------------------------------------
+
+// dot_with_sign_bits (qjl.rs:151-178): sum += values[i] * (bit i set ? +1 : -1), strictly sequential f32
+float orc_tq_dot_with_sign_bits(const float* values, const uint64_t* bits, size_t count) {
+  float sum = 0.0f;
+  for (size_t i = 0; i < count; i++) sum += values[i] * (((bits[i / 64] >> (i % 64)) & 1) ? 1.0f : -1.0f);
+  return sum;
+}
+
+// QjlProjector::project_query (qjl.rs:100-114) with the matrix given: out[i] = sum_j S[i][j] * q[j], sequential, unfused
+void orc_tq_qjl_project(const float* S, size_t dim, const float* q, float* out) {
+  for (size_t i = 0; i < dim; i++) {
+    float dot = 0.0f;
+    for (size_t j = 0; j < dim; j++) dot += S[i * dim + j] * q[j];
+    out[i] = dot;
+  }
+}
+
+// QjlProjector::compress (qjl.rs:36-62): bits[(dim + 63) / 64] (bit i = (S x)_i >= 0), *norm = l2_norm(x) (qjl.rs:180-182)
+void orc_tq_qjl_compress(const float* S, size_t dim, const float* x, uint64_t* bits, float* norm) {
+  float ss = 0.0f;
+  for (size_t i = 0; i < dim; i++) ss += x[i] * x[i];
+  *norm = std::sqrt(ss);
+  for (size_t w = 0; w < (dim + 63) / 64; w++) bits[w] = 0;
+  for (size_t i = 0; i < dim; i++) {
+    float dot = 0.0f;
+    for (size_t j = 0; j < dim; j++) dot += S[i * dim + j] * x[j];
+    if (dot >= 0.0f) bits[i / 64] |= (uint64_t)1 << (i % 64);
+  }
+}
+
+// QjlProjector::inner_product_fast (qjl.rs:120-131): sqrt(pi / 2) / dim * key_norm * sum
+float orc_tq_qjl_inner_product_fast(size_t dim, const float* projected_query, const uint64_t* bits, float key_norm) {
+  const float coeff = std::sqrt(1.57079632679489661923f) / (float)dim;   // std::f32::consts::FRAC_PI_2.sqrt() / dim
+  return coeff * key_norm * orc_tq_dot_with_sign_bits(projected_query, bits, dim);
+}
+
+// TurboQuantEngine::bytes_per_entry (quant.rs:176-186)
+size_t orc_tq_bytes_per_entry(size_t dim, int bits, int use_qjl) {
+  const size_t pd = orc_tq_padded_dim(dim), cb = orc_tq_packed_bytes(bits, pd);
+  return use_qjl ? cb + (pd + 63) / 64 * 8 + 4 : cb;
+}
+
+// TurboQuantEngine::compress with QJL (quant.rs:71-103): codes as orc_tq_compress, then the residual rotated - dequantized
+// through the projector.  qjl_bits[(padded_dim + 63) / 64]
+void orc_tq_compress_qjl(const float* x, size_t dim, int bits, const float* signs, const float* S, uint8_t* packed, uint64_t* qjl_bits,
+                         float* residual_norm) {
+  const size_t pd = orc_tq_padded_dim(dim);
+  std::vector<float> rot(pd), deq(pd), res(pd);
+  orc_tq_rotate(x, dim, signs, rot.data());
+  orc_tq_quantize_vector(pd, bits, rot.data(), pd, packed);
+  orc_tq_dequantize_vector(pd, bits, packed, pd, deq.data());
+  for (size_t i = 0; i < pd; i++) res[i] = rot[i] - deq[i];
+  orc_tq_qjl_compress(S, pd, res.data(), qjl_bits, residual_norm);
+}
+
+// attention_head for TurboQuantProd: the scores are attention_scores with the projector (quant.rs:133-168: polar + correction, the
+// query projected once); the V side is unchanged — the reference stores QJL bits for V rows too but never reads them
+// (kv_turboquant.rs:154-170 dequantizes V through the codebook only).  k_qjl: [kv_len][(pd + 63) / 64] words, k_norm: [kv_len]
+void orc_tq_attention_head_qjl(const float* query, const uint8_t* k_codes, const uint64_t* k_qjl, const float* k_norm, const uint8_t* v_codes,
+                               size_t kv_len, size_t dim, int bits, const float* signs_k, const float* signs_v, const float* S_k, float scale,
+                               float* out) {
+  const size_t pd = orc_tq_padded_dim(dim), pb = orc_tq_packed_bytes(bits, pd), nw = (pd + 63) / 64;
+  std::vector<float> rot_q(pd), proj_q(pd), scores(kv_len);
+  orc_tq_rotate(query, dim, signs_k, rot_q.data());
+  orc_tq_qjl_project(S_k, pd, rot_q.data(), proj_q.data());
+  for (size_t p = 0; p < kv_len; p++) {
+    const float polar = orc_tq_dot_with_packed(pd, bits, rot_q.data(), k_codes + p * pb, pd);
+    scores[p] = polar + orc_tq_qjl_inner_product_fast(pd, proj_q.data(), k_qjl + p * nw, k_norm[p]);
+  }
+  for (size_t p = 0; p < kv_len; p++) scores[p] *= scale;
+  if (kv_len) {
     float mx = -INFINITY;
     for (size_t p = 0; p < kv_len; p++) mx = std::fmax(mx, scores[p]);
     float sum = 0.0f;

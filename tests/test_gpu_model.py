@@ -678,6 +678,104 @@ def test_turboquant_kv_cache_follows_the_reference(pkg, orc, name, mix, n_tok, b
         ref.close()
 
 
+@pytest.mark.parametrize("name,mix,n_tok,bits", [("test-dense", "Q4_K_M", 70, 2), ("test-dense-d128", "Q4_K_M", 70, 3), ("test-moe", "Q5_K_M", 40, 2),
+                                                 ("test-dense-d128", "Q4_K_M", 700, 2)])
+def test_turboquant_prod_kv_cache_follows_the_reference(pkg, orc, name, mix, n_tok, bits):
+    """KVCacheType::TurboQuantProd { bits } — `--kv-cache-type tq2-qjl | tq3-qjl` (src/config.rs:808-817): the TurboQuant codes plus
+    the QJL correction of the attention scores (src/model/turboquant/qjl.rs, quant.rs:133-168) — against the oracle's restatement
+    with the SAME sign vectors and the SAME projection matrices on both sides (lgh_set_kv_qjl_matrices <-> QjlProjector's matrix).
+    Stored rows are bit-exact (test_gpu_ops.py::test_turboquant_qjl_rows_bit_exact); logits to the TurboQuant tolerance.  The K rows
+    carry head_dim / 8 + 4 more bytes (quant.rs:176-186; the reference also stores such bits for V rows and never reads them — they
+    are not kept here); shift_left / truncate move them with the codes."""
+    ktol = 4.0
+    max_seq = n_tok + 24
+    cfg = pkg.make_config(name, max_seq_len=max_seq)
+    model = pkg.SynthModel(cfg, mix=mix)
+    rng = np.random.default_rng(17 + bits)
+    signs = np.where(rng.integers(0, 2, cfg.num_layers * cfg.num_kv_heads * 2 * cfg.head_dim) == 1, 1.0, -1.0).astype(np.float32)
+    qjl = rng.standard_normal(cfg.num_layers * cfg.num_kv_heads * cfg.head_dim * cfg.head_dim).astype(np.float32)
+    ref = orc.Model(cfg.as_dict())
+    for nm, t, ne, data in model.tensors(keep=True):
+        ref.add_tensor(nm, t, ne, data)
+    ref.finalize()
+    ref.set_kv_turboquant(bits, signs)
+    ref.set_kv_turboquant_qjl(qjl)
+    hb = pkg.hip_backend
+    eng = pkg.HipGpuInference.from_model(model, max_seq, kv_cache_type=hb.KV_TQ2_QJL if bits == 2 else hb.KV_TQ3_QJL, kv_rotation_signs=signs,
+                                         kv_qjl_matrices=qjl)
+    mse = pkg.HipGpuInference.from_model(model, max_seq, kv_cache_type=hb.KV_TQ2 if bits == 2 else hb.KV_TQ3, kv_rotation_signs=signs)
+    n_rows = cfg.num_layers * cfg.num_kv_heads * max_seq
+    assert eng.stats()["kv_bytes"] == mse.stats()["kv_bytes"] + n_rows * (cfg.head_dim // 8 + 4)
+    try:
+        toks = [(41 * i + 7) % cfg.vocab_size for i in range(n_tok)]
+        check = set(range(8)) | {n_tok // 2, n_tok - 2, n_tok - 1} | set(range(60, 68))
+        worst, moved = 0.0, 0.0
+        if n_tok > 500:
+            bulk = toks[:n_tok - 6]
+            for t in bulk:
+                eng.prefill_token(t)
+                mse.prefill_token(t)
+            ref.forward(bulk[:-1])
+            ref.forward(bulk[-1:])
+            toks = toks[n_tok - 6:]
+            check = set(range(6))
+        for i, t in enumerate(toks):
+            got, want, plain = eng.forward(t), ref.forward([t]), mse.forward(t)
+            if i in check:
+                worst = max(worst, float(np.abs(got - want).max()) / _tol(want))
+                moved = max(moved, float(np.abs(got - plain).max()) / _tol(want))
+                assert np.abs(got - want).max() <= ktol * _tol(want), (i, float(np.abs(got - want).max()), _tol(want))
+        print(f"{name}/{mix} TurboQuant-prod {bits}-bit KV, {eng.position()} rows: max|dlogit| = {worst:.4f} x the f32 tolerance; "
+              f"the QJL correction moves the logits by up to {moved:.1f} x that tolerance")
+        assert moved > 1.0                                            # the correction is not a no-op
+        if n_tok <= 500:
+            for e in (eng, ref):
+                e.kv_shift_left(11)
+            assert eng.position() == ref.position
+            for t in (5, 6, 7):
+                got, want = eng.forward(t), ref.forward([t])
+                assert np.abs(got - want).max() <= ktol * _tol(want)
+            eng.kv_truncate(20)
+            ref.kv_truncate(20)
+            got, want = eng.forward(9), ref.forward([9])
+            assert np.abs(got - want).max() <= ktol * _tol(want)
+            pos = eng.position()
+            dev = eng.decode_greedy(3, 8).tolist()                    # graph replays == the host loop
+            eng.kv_truncate(pos)
+            host, tok = [], 3
+            for _ in range(8):
+                tok = orc.argmax_last(eng.forward(tok))
+                host.append(tok)
+            assert dev == host
+    finally:
+        eng.close()
+        mse.close()
+        ref.close()
+
+
+def test_turboquant_qjl_matrix_contract(pkg):
+    """lgh_set_kv_qjl_matrices: exactly [layers][kv heads][head_dim][head_dim] finite values, only on a TurboQuantProd context, only
+    before finalize; without it the context decodes with its deterministic stand-in."""
+    hb = pkg.hip_backend
+    cfg = pkg.make_config("test-dense-d128", max_seq_len=16)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    n = cfg.num_layers * cfg.num_kv_heads * cfg.head_dim * cfg.head_dim
+    bad_nan = np.ones(n, np.float32)
+    bad_nan[5] = np.nan
+    for bad in (np.ones(n - 1, np.float32), bad_nan):
+        with pytest.raises(pkg.BackendError) as ei:
+            pkg.HipGpuInference.from_model(model, 16, kv_cache_type=hb.KV_TQ2_QJL, kv_qjl_matrices=bad)
+        assert ei.value.variant == "InvalidArgument"
+    with pytest.raises(pkg.BackendError):
+        pkg.HipGpuInference.from_model(model, 16, kv_cache_type=hb.KV_TQ2, kv_qjl_matrices=np.ones(n, np.float32))   # an MSE context
+    eng = pkg.HipGpuInference.from_model(model, 16, kv_cache_type=hb.KV_TQ3_QJL)                                      # stand-ins
+    a = eng.forward(3)
+    b = eng.forward(4)
+    eng.reset()
+    assert np.array_equal(a, eng.forward(3)) and np.array_equal(b, eng.forward(4)) and np.all(np.isfinite(b))
+    eng.close()
+
+
 def test_turboquant_sign_vector_contract(pkg):
     """lgh_set_kv_rotation_signs: only +-1, exactly [layers][kv heads][2][head_dim] values, only on a TurboQuant context and only
     before finalize; without it the context decodes with its deterministic stand-in; head sizes the butterfly cannot take are

@@ -232,3 +232,25 @@ def test_turboquant_codes_bit_exact(gpu, orc, dim, bits):
             assert np.array_equal(got, want), (dim, bits, np.flatnonzero(got != want)[:4])
             n += 1
     assert n == 4 * len(rows)
+
+
+@pytest.mark.parametrize("dim,bits", [(64, 2), (128, 2), (128, 3), (64, 3)])
+def test_turboquant_qjl_rows_bit_exact(gpu, orc, dim, bits):
+    """TurboQuantEngine::compress with use_qjl (quant.rs:71-103 + QjlProjector::compress, qjl.rs:36-62) as the attention launch
+    applies it to a new K row (lgh_op_tq_compress_qjl): codes, the sign bits of S r and |r| equal the oracle's BIT FOR BIT for the
+    same projection matrix — residual = rotated - centroid in f32, every projection a sequential unfused dot product, the norm a
+    sequential sum of squares."""
+    rng = np.random.default_rng(900 + dim + bits)
+    S = rng.standard_normal((dim, dim)).astype(np.float32)
+    sg = np.where(rng.integers(0, 2, dim) == 1, 1.0, -1.0).astype(np.float32)
+    rows = [rng.standard_normal(dim).astype(np.float32) * s for s in (1.0 / np.sqrt(dim), 1.0, 1e-4, 30.0)]
+    rows += [np.zeros(dim, np.float32), np.full(dim, 0.37, np.float32), (np.arange(dim, dtype=np.float32) - dim / 2) * np.float32(0.01)]
+    for x in rows:
+        codes, qb, nrm = gpu.op_tq_compress_qjl(x, bits, sg, S)
+        wc, wb, wn = orc.tq_compress_qjl(x, bits, sg, S)
+        assert np.array_equal(codes, wc)
+        assert np.array_equal(qb, wb), (dim, bits, [hex(int(v)) for v in qb], [hex(int(v)) for v in wb])
+        assert np.float32(nrm).view(np.uint32) == np.float32(wn).view(np.uint32), (nrm, wn)
+    # a zero projection matrix: every projection is +0.0 >= 0 -> all bits set (qjl.rs:58-60)
+    codes, qb, nrm = gpu.op_tq_compress_qjl(rows[0], bits, sg, np.zeros((dim, dim), np.float32))
+    assert all(int(v) == 2**64 - 1 for v in qb)

@@ -452,3 +452,122 @@ def test_turboquant_kv_cache_kats(orc):
     x = (np.arange(64, dtype=np.float32) - np.float32(32.0)) * np.float32(0.01)         # test_mse_compress_decompress input
     assert np.array_equal(orc.tq_compress(x, 2, sk), orc.tq_quantize_vector(64, 2, orc.tq_rotate(x, sk)))
     assert orc.tq_compress(x, 3, sk).size == 24
+
+
+def _gauss(dim, seed):
+    """A QJL projection matrix S[dim][dim] ~ N(0, 1) (an INPUT of the oracle and of the library: the reference draws it from
+    rand's StdRng + rand_distr::StandardNormal, qjl.rs:44-52, which is not restated)."""
+    return np.random.default_rng(seed).standard_normal((dim, dim)).astype(np.float32)
+
+
+def test_turboquant_qjl_kats(orc):
+    """TurboQuantProd (tq2-qjl / tq3-qjl): the reference's own deterministic unit tests of the sign-bit dot product (qjl.rs:236-250,
+    backend/cpu/simd.rs:1286-1350) and of the entry size (quant.rs:340-352); the seeded-RNG tests (qjl.rs:186-234) as properties
+    over matrices drawn here."""
+    # test_dot_with_sign_bits_all_positive / _alternating
+    assert orc.tq_dot_with_sign_bits([1, 2, 3, 4], [0xF], 4) == 10.0
+    assert orc.tq_dot_with_sign_bits([1, 2, 3, 4], [0b0101], 4) == 1.0 - 2.0 + 3.0 - 4.0
+    # simd.rs: test_dot_sign_bits_fast_basic / all_ones / all_zeros / odd_count / (1286-1300) alternating over 128
+    assert orc.tq_dot_with_sign_bits([1, 2, 3, 4], [0b1010], 4) == 2.0
+    v = np.arange(1, 129, dtype=np.float32)
+    assert abs(orc.tq_dot_with_sign_bits(v, [2**64 - 1, 2**64 - 1], 128) - float(v.sum())) < 1e-2
+    assert orc.tq_dot_with_sign_bits(np.ones(64, np.float32), [0], 64) == -64.0
+    assert orc.tq_dot_with_sign_bits([1, 2, 3, 4, 5, 6, 7], [0b1111111], 7) == 28.0
+    alt = int("01" * 32, 2)                                                             # even bits set: +, -, +, - ...
+    want = np.float32(0.0)
+    for i in range(128):
+        want = np.float32(want + v[i] * np.float32(1.0 if i % 2 == 0 else -1.0))
+    assert orc.tq_dot_with_sign_bits(v, [alt, alt], 128) == float(want)
+    # test_bytes_per_entry
+    assert orc.tq_bytes_per_entry(128, 2, False) == 128 // 4
+    assert orc.tq_bytes_per_entry(128, 2, True) == 128 // 4 + (128 + 63) // 64 * 8 + 4
+    assert orc.tq_bytes_per_entry(80, 3, True) == 48 + 16 + 4                            # padded to 128
+    # test_compress_produces_correct_shape: 128 -> 2 words, norm > 0; the bits are the signs of S x, the norm is |x|
+    S = _gauss(128, 42)
+    x = (np.arange(128, dtype=np.float32) - np.float32(64.0)) * np.float32(0.01)
+    bits, norm = orc.tq_qjl_compress(S, x)
+    assert bits.size == 2 and norm > 0.0 and abs(norm - float(np.linalg.norm(x.astype(np.float64)))) < 1e-5
+    z = S.astype(np.float64) @ x.astype(np.float64)
+    got = np.array([(int(bits[i // 64]) >> (i % 64)) & 1 for i in range(128)])
+    safe = np.abs(z) > 1e-4                                                             # away from the f32 / f64 rounding boundary
+    assert np.array_equal(got[safe], (z >= 0)[safe].astype(int)) and safe.sum() > 120
+    # test_fast_matches_slow: inner_product (projects the query row by row) == project_query + inner_product_fast
+    S32 = _gauss(32, 99)
+    key = np.arange(32, dtype=np.float32) * np.float32(0.02)
+    query = (np.arange(32, dtype=np.float32) - np.float32(16.0)) * np.float32(0.01)
+    kb, kn = orc.tq_qjl_compress(S32, key)
+    pq = orc.tq_qjl_project(S32, query)
+    fast = orc.tq_qjl_inner_product_fast(pq, kb, kn)
+    slow = np.float32(0.0)
+    for i in range(32):
+        slow = np.float32(slow + pq[i] * np.float32(1.0 if (int(kb[0]) >> i) & 1 else -1.0))
+    slow = np.float32(np.float32(np.sqrt(np.float32(np.pi / 2)) / np.float32(32)) * np.float32(kn)) * slow
+    assert abs(float(slow) - fast) < 1e-6
+    # test_inner_product_unbiased / test_inner_product_right_ballpark as a property: over many matrices the estimate's mean
+    # converges to the true inner product (the estimator is unbiased: E[sqrt(pi/2)/d * |k| * sum_i (S q)_i sign((S k)_i)] = <q, k>)
+    dim = 64
+    xk = (np.arange(dim, dtype=np.float32) - np.float32(32.0)) * np.float32(0.01)
+    yq = np.arange(dim, dtype=np.float32) * np.float32(0.01)
+    true = float(xk.astype(np.float64) @ yq.astype(np.float64))
+    est = []
+    for seed in range(200):
+        Sm = _gauss(dim, 1000 + seed)
+        b, n = orc.tq_qjl_compress(Sm, xk)
+        est.append(orc.tq_qjl_inner_product_fast(orc.tq_qjl_project(Sm, yq), b, n))
+    est = np.array(est)
+    assert abs(est.mean() - true) < 4 * est.std() / np.sqrt(len(est)) + 1e-3, (est.mean(), true, est.std())
+    assert np.all(np.abs(est - true) / abs(true) < 2.0)                                  # "in the right ballpark", every draw
+
+
+def test_turboquant_prod_engine_kats(orc):
+    """TurboQuantEngine with use_qjl (quant.rs:71-168): compress = MSE codes + QJL of the residual; attention_score = polar +
+    correction; the correction shrinks the score error of the codes on average (what TurboQuant_prod is for)."""
+    dim, bits = 64, 2
+    sk, sv = _signs(64, 1), _signs(64, 2)
+    S = _gauss(64, 7)
+    x = (np.arange(64, dtype=np.float32) - np.float32(32.0)) * np.float32(0.01)         # test_prod_compress_has_qjl input
+    codes, qb, rn = orc.tq_compress_qjl(x, bits, sk, S)
+    assert np.array_equal(codes, orc.tq_compress(x, bits, sk))                          # the MSE part is unchanged
+    rot = orc.tq_rotate(x, sk)
+    res = rot - orc.tq_dequantize_vector(64, bits, codes, 64)                           # f32 subtraction, as quant.rs:85-89
+    b2, n2 = orc.tq_qjl_compress(S, res)
+    assert np.array_equal(qb, b2) and rn == n2 and rn > 0.0
+    # one cached position: attention output = that position's decompressed V row, whatever the score
+    v = np.linspace(-1, 1, 64).astype(np.float32)
+    vcodes = orc.tq_compress(v, bits, sv)
+    scale = float(np.float32(1.0) / np.sqrt(np.float32(64.0)))
+    out = orc.tq_attention_head_qjl(x, codes, qb, [rn], vcodes, 1, bits, sk, sv, S, scale)
+    assert np.array_equal(out, orc.tq_rotate_inverse(orc.tq_dequantize_vector(64, bits, vcodes, 64), 64, sv))
+    # scores: polar + correction (quant.rs:152-166) against the true inner product, unit-norm rows (the codebook's regime)
+    rng = np.random.default_rng(5)
+    err_mse, err_prod = [], []
+    for t in range(64):
+        k = rng.standard_normal(64).astype(np.float32); k /= np.float32(np.linalg.norm(k))
+        q = rng.standard_normal(64).astype(np.float32); q /= np.float32(np.linalg.norm(q))
+        Sm = _gauss(64, 100 + t)
+        c, b, n = orc.tq_compress_qjl(k, bits, sk, Sm)
+        rq = orc.tq_rotate(q, sk)
+        polar = orc.tq_dot_with_packed(64, bits, rq, c, 64)
+        corr = orc.tq_qjl_inner_product_fast(orc.tq_qjl_project(Sm, rq), b, n)
+        true = float(k.astype(np.float64) @ q.astype(np.float64))
+        err_mse.append(polar - true)
+        err_prod.append(polar + corr - true)
+    # the MSE codes shrink inner products (biased towards 0); the correction removes the bias: mean error closer to 0
+    assert abs(np.mean(err_prod)) <= abs(np.mean(err_mse)) + 0.02
+    # two positions: softmax over (polar + correction) * scale, output = convex combination of the decompressed V rows
+    k0 = rng.standard_normal(64).astype(np.float32); k0 /= np.float32(np.linalg.norm(k0))
+    k1 = -k0
+    c0, b0, n0 = orc.tq_compress_qjl(k0, bits, sk, S)
+    c1, b1, n1 = orc.tq_compress_qjl(k1, bits, sk, S)
+    v0, v1 = np.full(64, 1.0, np.float32), np.full(64, 2.0, np.float32)
+    vc = np.concatenate([orc.tq_compress(v0, bits, sv), orc.tq_compress(v1, bits, sv)])
+    out = orc.tq_attention_head_qjl(k0, np.concatenate([c0, c1]), np.concatenate([b0, b1]), [n0, n1], vc, 2, bits, sk, sv, S, 1.0)
+    rq = orc.tq_rotate(k0, sk)
+    pq = orc.tq_qjl_project(S, rq)
+    s = [np.float32(np.float32(orc.tq_dot_with_packed(64, bits, rq, c, 64)) + np.float32(orc.tq_qjl_inner_product_fast(pq, b, n)))
+         for c, b, n in ((c0, b0, n0), (c1, b1, n1))]
+    assert s[0] > s[1]
+    e = np.exp(np.array(s, np.float32) - max(s))
+    w = e / np.float32(e[0] + e[1])
+    d = [orc.tq_rotate_inverse(orc.tq_dequantize_vector(64, bits, vc[16 * i: 16 * i + 16], 64), 64, sv) for i in range(2)]
+    assert np.allclose(out, w[0] * d[0] + w[1] * d[1], rtol=1e-6, atol=1e-7)
