@@ -380,8 +380,9 @@ def run_batch(args, pkg):
         "roofline": {"bound": "hbm", "achieved": round(step_bytes * (K / elapsed) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(step_bytes * (K / elapsed) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                      "alg_bytes_per_step": int(step_bytes), "alg_bytes_per_token": int(step_bytes / B),
-                     "note": "whole step: weights once + B x (KV rows + logits + vectors); at large B the step is bound by the vector ALU "
-                             "(one MFMA group + ~60 vector instructions per tile and sequence), not by HBM"},
+                     "note": "whole step: weights once + B x (KV rows + logits + vectors); from ~4 sequences on the step is bound by the "
+                             "matrix-core + vector-ALU work per (tile, sequence) — 4 MFMAs + ~42 vector instructions, the price of "
+                             "bit-identical f32-exact activations — not by HBM (profiles/r03e_batched_decode.md)"},
         "load_seconds": round(load_s, 1)}))
     eng.close()
     single.close()

@@ -159,6 +159,8 @@ struct MvBatch {
   uint32_t resid_stride[3];
   uint32_t xq_out_stride[3];  // bytes
   uint32_t ssq_out_stride[3];
+  float* part;                // mvqb2: partial sums [slot][sequence][unit * 16 + row] between the two launches of an op
+  uint64_t part_floats;
 };
 
 // launch-uniform geometry of one int8-MFMA launch as the kernel takes it (mvq_pack)

@@ -55,7 +55,8 @@ struct BatchScratch {
   uint32_t max_batch = 0, ffn = 0;
   uint64_t cache_stride = 0;                          // floats between two slots' caches of one layer
   float *hidden = nullptr, *xnorm = nullptr, *q = nullptr, *attn_out = nullptr, *act = nullptr, *act2 = nullptr, *logits = nullptr,
-        *part_ml = nullptr, *part_acc = nullptr, *amax_v = nullptr, *moe_w = nullptr;
+        *part_ml = nullptr, *part_acc = nullptr, *amax_v = nullptr, *moe_w = nullptr, *mv_part = nullptr;
+  uint64_t mv_part_floats = 0;
   int *amax_i = nullptr, *moe_sel = nullptr;
   int *d_tokens = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_log = nullptr;   // the step's control words (device), the greedy token log
   int* h_ctl = nullptr;                               // pinned staging of the control words

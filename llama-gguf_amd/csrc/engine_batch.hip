@@ -91,6 +91,8 @@ int launch_mvb(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float*
   B.pos = Bs.d_pos;
   B.slot = Bs.d_slot;
   B.cache_stride = Bs.cache_stride;
+  B.part = Bs.mv_part;
+  B.part_floats = Bs.mv_part_floats;
   {   // the input vector's images lie at the strides its views were registered with
     const XqBuf* q0 = view_of(c, specs[0].x[0]);
     const uint32_t kreg = q0 ? q0->k : k;
@@ -328,12 +330,16 @@ int lgh_batch_create(lgh_ctx* c, uint32_t max_batch) {
   Bs.ffn = ffn;
   Bs.cache_stride = (uint64_t)d.num_kv_heads * d.max_seq_len * d.head_dim;
   const size_t B = max_batch;
+  // partial sums between the two launches of a multi-sequence mat-vec (matvec_batch.hip, mvqb2): per sequence either one value per
+  // launch row (any matrix) or 8 slices x the rows of a matrix with fewer than 1600 row tiles
+  Bs.mv_part_floats = B * std::max<uint64_t>({(uint64_t)8 * 1600 * 16, (uint64_t)d.vocab_size + 16, (uint64_t)2 * ffn, (uint64_t)QD + 2 * d.num_kv_heads * d.head_dim});
   uint8_t *xq_h = nullptr, *xq_a = nullptr, *xq_f = nullptr, *xq_f2 = nullptr;
   float *ssq_h = nullptr, *ssq_a = nullptr, *ssq_f = nullptr, *ssq_f2 = nullptr;
   struct { void** p; size_t n; } bufs[] = {
       {(void**)&Bs.hidden, B * H * 4},   {(void**)&Bs.xnorm, B * H * 4},   {(void**)&Bs.q, B * QD * 4},   {(void**)&Bs.attn_out, B * QD * 4},
       {(void**)&Bs.act, B * ffn * 4},    {(void**)&Bs.act2, B * ffn * 4},  {(void**)&Bs.logits, B * d.vocab_size * 4},
       {(void**)&Bs.part_ml, B * d.num_kv_heads * c->n_splits * G * 2 * 4}, {(void**)&Bs.part_acc, B * d.num_kv_heads * c->n_splits * G * d.head_dim * 4},
+      {(void**)&Bs.mv_part, Bs.mv_part_floats * 4},
       {(void**)&Bs.amax_v, B * 64 * 4},  {(void**)&Bs.amax_i, B * 64 * 4}, {(void**)&Bs.moe_sel, B * 8 * 4}, {(void**)&Bs.moe_w, B * 8 * 4},
       {(void**)&Bs.d_tokens, kMaxBatch * 4}, {(void**)&Bs.d_pos, kMaxBatch * 4}, {(void**)&Bs.d_slot, kMaxBatch * 4},
       {(void**)&Bs.d_log, (size_t)d.max_seq_len * kMaxBatch * 4},

@@ -262,14 +262,34 @@ __device__ __forceinline__ void mvq_unpack_tile(int fmt, const RawT16& r, uint32
   }
 }
 
+// mvq_mac_tile in its two phases — the four matrix-core products, then everything the vector ALU does with them — so that a caller
+// can put other sequences' products between a sequence's two phases (matvec_batch.hip, mvqb2).  Same operations, same order.
+struct MacD { i32x4 d[4]; };
+
+__device__ __forceinline__ void mvq_mac_mfma(const TileOps& t, const i32x4 (&a)[4], MacD& m) {
+  const i32x4 zero = {0, 0, 0, 0};
+#pragma unroll
+  for (int pp = 0; pp < 4; pp++) m.d[pp] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[pp], t.bw[pp], zero, 0, 0, 0);
+}
+
+template <uint32_t MASK>
+__device__ __forceinline__ void mvq_mac_finish(int fmt, const TileOps& t, const MacD& m, const f32x4 xs, const f32x4 sx, float& acc);
+
 template <uint32_t MASK>
 __device__ __forceinline__ void mvq_mac_tile(int fmt, const TileOps& t, const XqOps& o, float& acc) {
+  MacD m;
+  mvq_mac_mfma(t, o.a, m);
+  mvq_mac_finish<MASK>(fmt, t, m, o.xs, o.sx, acc);
+}
+
+template <uint32_t MASK>
+__device__ __forceinline__ void mvq_mac_finish(int fmt, const TileOps& t, const MacD& m, const f32x4 xs, const f32x4 sx, float& acc) {
   auto is = [&](int f) { return mvq_is<MASK>(fmt, f); };
-  const i32x4 zero = {0, 0, 0, 0};
+  struct { f32x4 xs, sx; } o{xs, sx};
   float V[4];
 #pragma unroll
   for (int pp = 0; pp < 4; pp++) {
-    const i32x4 d = __builtin_amdgcn_mfma_i32_16x16x64_i8(o.a[pp], t.bw[pp], zero, 0, 0, 0);
+    const i32x4 d = m.d[pp];
     const float hi = (float)((d.x << 8) + d.y), lo = (float)((d.z << 8) + d.w);
     V[pp] = __builtin_fmaf(hi, 65536.0f, lo);
   }
