@@ -463,7 +463,9 @@ def run_pipeline(args, pkg):
     dec.decode_device(prompt[-1], 1 + W, collect=False)   # the prompt's last token + W warm-up steps; the next token stays on device
     kv0 = stage.position()
     rep_s = []
-    for _ in range(reps):                                  # each repetition: exactly K steps, barrier + device sync on both sides
+    for r in range(reps):                                  # each repetition: exactly K steps, barrier + device sync on both sides
+        if r > 0 and not fake:
+            eng.kv_truncate(kv0)                           # ... from the same cache state on every stage (the fed-back token stays on device)
         sync()
         dist.barrier()
         t0 = time.perf_counter()
@@ -521,18 +523,19 @@ def run_inlib(args, pkg):
     devices = [min(s * args.gpus // stages, n_dev - 1) for s in range(stages)]
     W, K = args.warmup, args.steps
     reps = max(args.reps, 1)
-    max_seq = max(512, args.prompt + W + reps * K + 16)
+    max_seq = max(512, args.prompt + W + K + 16)
     cfg = pkg.make_config(args.model, max_seq_len=max_seq)
     model = pkg.SynthModel(cfg, mix=args.mix)
     eng = pkg.HipPipeline.from_model(model, max_seq, stages, devices=devices, flags=args.flags)
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
     for t in prompt[:-1]:
         eng.prefill_token(t)
-    eng.forward(prompt[-1])
-    tok = int(eng.decode_greedy(prompt[-1], W)[-1]) if W > 0 else prompt[-1]
+    tok0 = int(eng.decode_greedy(prompt[-1], 1 + W)[-1])   # the prompt's last token + W warm-up steps (as the other modes)
     kv0 = eng.position()
     rep_s = []
     for _ in range(reps):
+        eng.kv_truncate(kv0)                               # every repetition: the same K steps from the same cache state
+        tok = tok0
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tok = int(eng.decode_greedy(tok, K)[-1])       # returns after every stage's stream has drained

@@ -351,6 +351,7 @@ int lgh_pipeline_prefill_token(lgh_pipeline* p, uint32_t token_id);             
 int lgh_pipeline_decode_greedy(lgh_pipeline* p, uint32_t first_token, size_t n_steps, uint32_t* tokens_out);
 void lgh_pipeline_reset(lgh_pipeline* p);                                             /* GpuInference::reset */
 size_t lgh_pipeline_position(const lgh_pipeline* p);                                  /* GpuInference::position */
+int lgh_pipeline_kv_truncate(lgh_pipeline* p, size_t new_len);                         /* lgh_kv_truncate on every stage */
 int lgh_pipeline_stages(const lgh_pipeline* p);
 const char* lgh_pipeline_last_error(const lgh_pipeline* p);
 

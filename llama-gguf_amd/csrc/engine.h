@@ -40,6 +40,7 @@ struct PfScratch {
   int* tokens = nullptr;
   uint32_t* tok_pinned = nullptr;      // pinned host staging of the prompt's token ids, one slot per position
   hipEvent_t tok_copied = nullptr;     // recorded behind the last copy out of it
+  uint32_t tok_lo = 0, tok_hi = 0;     // slots [tok_lo, tok_hi) may still be read by a copy enqueued since the last wait for tok_copied
   // MoE layers: routing of the block's tokens, tokens grouped by expert, one expert's gathered input, per-slot expert outputs
   int *moe_sel = nullptr, *moe_cnt = nullptr, *moe_base = nullptr, *moe_list = nullptr, *moe_rowmap = nullptr, *moe_tokmap = nullptr;
   float* moe_w = nullptr;

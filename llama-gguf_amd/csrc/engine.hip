@@ -862,9 +862,14 @@ static int prefill_block(lgh_ctx* c, const uint32_t* tokens, uint32_t m) {
     if (!P.tok_pinned) {
       HIP_TRY(c, LGH_ALLOCATION_FAILED, hipHostMalloc((void**)&P.tok_pinned, (size_t)d.max_seq_len * 4, hipHostMallocDefault));
       HIP_TRY(c, LGH_OPERATION_FAILED, hipEventCreateWithFlags(&P.tok_copied, hipEventDisableTiming));
-    } else {
+    } else if (pos0 < P.tok_hi && pos0 + m > P.tok_lo) {
+      // only when a slot about to be rewritten may still be read: a reset / shift / truncate followed by a new prompt.  The blocks
+      // of ONE prompt use ascending slots and never wait here (lgh_stage_prefill_batch stays asynchronous).
       HIP_TRY(c, LGH_OPERATION_FAILED, hipEventSynchronize(P.tok_copied));
+      P.tok_lo = P.tok_hi = 0;
     }
+    if (P.tok_hi == P.tok_lo) { P.tok_lo = pos0; P.tok_hi = pos0 + m; }
+    else { P.tok_lo = std::min(P.tok_lo, pos0); P.tok_hi = std::max(P.tok_hi, pos0 + m); }
     std::memcpy(P.tok_pinned + pos0, tokens, (size_t)m * 4);
     HIP_TRY(c, LGH_OPERATION_FAILED, hipMemcpyAsync(P.tokens, P.tok_pinned + pos0, (size_t)m * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(c, LGH_OPERATION_FAILED, hipEventRecord(P.tok_copied, st));

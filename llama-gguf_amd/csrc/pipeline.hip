@@ -279,6 +279,18 @@ void lgh_pipeline_reset(lgh_pipeline* p) {
   p->pos = 0;
 }
 
+// KVCache::truncate on every stage (src/model/mod.rs: the positions from new_len on are forgotten)
+int lgh_pipeline_kv_truncate(lgh_pipeline* p, size_t new_len) {
+  if (!p) return LGH_INVALID_ARGUMENT;
+  if (new_len > p->pos) return pfail(p, LGH_INVALID_ARGUMENT, "new_len exceeds the current position");
+  for (size_t s = 0; s < p->stage.size(); s++) {
+    const int rc = lgh_kv_truncate(p->stage[s], new_len);
+    if (rc) return stage_fail(p, s, rc);
+  }
+  p->pos = new_len;
+  return LGH_OK;
+}
+
 size_t lgh_pipeline_position(const lgh_pipeline* p) { return p ? p->pos : 0; }
 
 int lgh_pipeline_stages(const lgh_pipeline* p) { return p ? (int)p->stage.size() : 0; }

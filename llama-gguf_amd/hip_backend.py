@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "lgh_op_swiglu_vec_mat", "lgh_bench_vec_mat", "lgh_bench_hbm_read", "lgh_gguf_inspect", "lgh_load_gguf",
     "lgh_stage_io_buffers", "lgh_stage_set_forward_targets", "lgh_stage_step", "lgh_stage_read_tokens", "lgh_gguf_get", "lgh_stage_read_logits",
     "lgh_pipeline_create", "lgh_pipeline_upload_tensor", "lgh_pipeline_finalize", "lgh_pipeline_destroy", "lgh_pipeline_forward",
-    "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_stages",
+    "lgh_pipeline_prefill_token", "lgh_pipeline_decode_greedy", "lgh_pipeline_reset", "lgh_pipeline_position", "lgh_pipeline_kv_truncate", "lgh_pipeline_stages",
     "lgh_pipeline_last_error",
     "lgh_set_kv_rotation_signs", "lgh_op_tq_compress", "lgh_set_kv_qjl_matrices", "lgh_op_tq_compress_qjl",
     "lgh_batch_create", "lgh_batch_reset", "lgh_batch_position", "lgh_batch_prefill", "lgh_forward_multi", "lgh_decode_greedy_multi",
@@ -159,7 +159,7 @@ def load_library() -> C.CDLL:
         "lgh_pipeline_finalize": (C.c_int, [vp]), "lgh_pipeline_destroy": (None, [vp]),
         "lgh_pipeline_forward": (C.c_int, [vp, u32, vp]), "lgh_pipeline_prefill_token": (C.c_int, [vp, u32]),
         "lgh_pipeline_decode_greedy": (C.c_int, [vp, u32, sz, vp]), "lgh_pipeline_reset": (None, [vp]),
-        "lgh_pipeline_position": (sz, [vp]), "lgh_pipeline_stages": (C.c_int, [vp]), "lgh_pipeline_last_error": (C.c_char_p, [vp]),
+        "lgh_pipeline_position": (sz, [vp]), "lgh_pipeline_kv_truncate": (C.c_int, [vp, sz]), "lgh_pipeline_stages": (C.c_int, [vp]), "lgh_pipeline_last_error": (C.c_char_p, [vp]),
         "lgh_set_kv_rotation_signs": (C.c_int, [vp, vp, sz]), "lgh_op_tq_compress": (C.c_int, [C.c_int, C.c_int, vp, sz, vp, vp]),
         "lgh_set_kv_qjl_matrices": (C.c_int, [vp, vp, sz]), "lgh_op_tq_compress_qjl": (C.c_int, [C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp]),
         "lgh_batch_create": (C.c_int, [vp, u32]), "lgh_batch_reset": (C.c_int, [vp, u32]), "lgh_batch_position": (sz, [vp, u32]),
@@ -478,6 +478,9 @@ class HipPipeline:
 
     def position(self) -> int:
         return load_library().lgh_pipeline_position(self._h)
+
+    def kv_truncate(self, new_len: int) -> None:
+        self._call(load_library().lgh_pipeline_kv_truncate(self._h, int(new_len)))
 
     def stages(self) -> int:
         return load_library().lgh_pipeline_stages(self._h)
