@@ -46,13 +46,19 @@ struct HostTensor {
 class HipGpuInference {
  public:
   // pub fn from_model(model: LlamaModel, max_seq_len: usize) -> BackendResult<Self>
-  static HipGpuInference from_model(lgh_model_desc desc, const std::vector<HostTensor>& tensors, size_t max_seq_len) {
+  // kv_rotation_signs / kv_qjl_matrices: what a TurboQuant KV cache (desc.kv_cache_type LGH_KV_TQ*; `--kv-cache-type tq2 | tq3 |
+  // tq2-qjl | tq3-qjl`) draws from its seeded RNG in the reference — HadamardRotation::signs() of every (layer, kv head, K / V) engine
+  // and the K engines' QjlProjector matrices (src/model/kv_turboquant.rs:44-71) — as data; empty = the library's stand-ins
+  static HipGpuInference from_model(lgh_model_desc desc, const std::vector<HostTensor>& tensors, size_t max_seq_len,
+                                    const std::vector<float>& kv_rotation_signs = {}, const std::vector<float>& kv_qjl_matrices = {}) {
     desc.struct_size = sizeof(lgh_model_desc);
     desc.max_seq_len = (uint32_t)max_seq_len;
     lgh_ctx* h = nullptr;
     int rc = lgh_create(&desc, &h);
     if (rc) throw BackendError(rc, "lgh_create");
     HipGpuInference g(h, desc.vocab_size);
+    if (!kv_rotation_signs.empty()) g.check(lgh_set_kv_rotation_signs(h, kv_rotation_signs.data(), kv_rotation_signs.size()));
+    if (!kv_qjl_matrices.empty()) g.check(lgh_set_kv_qjl_matrices(h, kv_qjl_matrices.data(), kv_qjl_matrices.size()));
     for (const HostTensor& t : tensors) g.check(lgh_upload_tensor(h, t.name.c_str(), t.ggml_type, t.ne, t.data, t.nbytes));
     g.check(lgh_finalize(h));
     return g;
@@ -85,6 +91,33 @@ class HipGpuInference {
     return next;
   }
   lgh_ctx* handle() { return h_; }
+
+  // ---- the device side of BatchedEngine (src/engine_batched.rs:23-194, 200-330, 355-400): a slot = one ActiveSequence's
+  // InferenceContext; one step reads the weights once for all listed slots, every sequence gets the single-sequence logits bit for bit
+  void batch_create(uint32_t max_batch) { check(lgh_batch_create(h_, max_batch)); }     // BatchedEngineConfig::max_batch_size
+  void batch_reset(uint32_t slot) { check(lgh_batch_reset(h_, slot)); }                 // create_active_sequence: model.create_context()
+  size_t batch_position(uint32_t slot) { return lgh_batch_position(h_, slot); }
+  void batch_prefill(uint32_t slot, const std::vector<uint32_t>& tokens) { check(lgh_batch_prefill(h_, slot, tokens.data(), tokens.size())); }
+  // step (engine_batched.rs:236-290): logits[i] for slots[i] fed tokens[i]; next_tokens (optional) = the bench's arg-max rule per sequence
+  std::vector<std::vector<float>> forward_multi(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& tokens,
+                                                std::vector<uint32_t>* next_tokens = nullptr) {
+    if (slots.size() != tokens.size()) throw std::invalid_argument("slots and tokens differ in length");
+    std::vector<float> flat(slots.size() * (size_t)vocab_);
+    if (next_tokens) next_tokens->assign(slots.size(), 0);
+    check(lgh_forward_multi(h_, slots.data(), tokens.data(), (uint32_t)slots.size(), flat.data(), next_tokens ? next_tokens->data() : nullptr));
+    std::vector<std::vector<float>> out(slots.size());
+    for (size_t i = 0; i < slots.size(); i++) out[i].assign(flat.begin() + i * vocab_, flat.begin() + (i + 1) * vocab_);
+    return out;
+  }
+  // n_steps greedy steps with the tokens fed back on the device: out[step][i]
+  std::vector<std::vector<uint32_t>> decode_greedy_multi(const std::vector<uint32_t>& slots, const std::vector<uint32_t>& first_tokens, size_t n_steps) {
+    if (slots.size() != first_tokens.size()) throw std::invalid_argument("slots and tokens differ in length");
+    std::vector<uint32_t> flat(n_steps * slots.size());
+    check(lgh_decode_greedy_multi(h_, slots.data(), first_tokens.data(), (uint32_t)slots.size(), n_steps, flat.data()));
+    std::vector<std::vector<uint32_t>> out(n_steps);
+    for (size_t s = 0; s < n_steps; s++) out[s].assign(flat.begin() + s * slots.size(), flat.begin() + (s + 1) * slots.size());
+    return out;
+  }
 
  private:
   HipGpuInference(lgh_ctx* h, uint32_t vocab) : h_(h), vocab_(vocab) {}

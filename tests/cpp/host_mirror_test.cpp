@@ -57,6 +57,20 @@ int main() {
     }
     try { model.gpu().forward(V); std::puts("ERR no exception"); return 4; }
     catch (const BackendError& e) { std::printf("error-variant %s\n", e.variant().c_str()); }
+    // the device side of BatchedEngine through the mirror: two slots with different histories; slot 1 replays the single-sequence
+    // run above token by token (slot 0 joins late, through the batched prompt path), so its logits equal the first line printed
+    // above (to rounding: below 64 rows the single-sequence engine uses its one-launch attention, another summation tree)
+    HipGpuInference& g = model.gpu();
+    g.batch_create(2);
+    for (uint32_t t : {3u, 17u, 255u, 9u}) g.forward_multi({1}, {t});
+    g.batch_prefill(0, {5, 6});
+    std::vector<uint32_t> nxt;
+    std::vector<std::vector<float>> lm = g.forward_multi({1, 0}, {700, 7}, &nxt);
+    std::printf("multi pos %zu %zu next %u %u :", g.batch_position(1), g.batch_position(0), nxt[0], nxt[1]);
+    for (uint32_t i = 0; i < V; i++) std::printf(" %a", lm[0][i]);
+    std::printf("\n");
+    std::vector<std::vector<uint32_t>> dev = g.decode_greedy_multi({1, 0}, {nxt[0], nxt[1]}, 3);
+    std::printf("multi-greedy %u %u %u\n", dev[0][0], dev[1][0], dev[2][0]);
   } catch (const BackendError& e) {
     std::fprintf(stderr, "BackendError %s\n", e.what());
     return 2;

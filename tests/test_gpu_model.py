@@ -213,6 +213,16 @@ def test_cpp_host_mirror(pkg, orc, tmp_path):
         assert int(head.split()[-1]) == orc.argmax_last(want) == orc.argmax_last(got)
         toks = [orc.argmax_last(want)]
     assert out[4] == "error-variant InvalidArgument"
+    # BatchedEngine's device side through the mirror: slot 1 replays the single-sequence history token by token -> the step-0 logits
+    # (to rounding), and its device-fed greedy tokens
+    head, vals = out[5].split(":")
+    got = np.array([float.fromhex(v) for v in vals.split()], dtype=np.float32)
+    first = np.array([float.fromhex(v) for v in out[0].split(":")[1].split()], dtype=np.float32)
+    assert head.split()[:4] == ["multi", "pos", "5", "3"]
+    assert np.abs(got - first).max() <= 1e-4 * float(np.abs(first).max())
+    assert int(head.split()[5]) == orc.argmax_last(got)
+    greedy = [int(v) for v in out[6].split()[1:]]
+    assert greedy[0] == int(out[1].split(":")[0].split()[-1]) and len(greedy) == 3
 
 
 def test_full_size_llama3_8b_q4_k_m_matches_oracle(pkg, orc):
