@@ -481,7 +481,6 @@ __global__ void __launch_bounds__(256) pf_resid_kernel(const float* __restrict__
     f32x4 v0 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i), v1 = *reinterpret_cast<const f32x4*>(hidden + (size_t)t * H + i + 4);
     if (S) {
       f32x4 a0 = (f32x4)(0.0f), a1 = (f32x4)(0.0f);
-#pragma unroll 8   // (eight splits' loads in flight; the additions keep their order)
       for (uint32_t s = 0; s < S; s++) {
         const float* row = part + ((size_t)s * kPfTokens + t) * ncols + col0 + i;
         if (moe_w) {   // MoeLayer::forward (moe.rs:363-368): zero-initialised, += routing weight * expert output in selection order
@@ -545,7 +544,6 @@ __global__ void __launch_bounds__(256) pf_qkv_epi_kernel(const float* __restrict
     const uint32_t i = rot ? (neox ? pr % half : (2 * pr % head_dim) / 2) : 0;
     const uint32_t r0 = rot && neox ? (pr / half) * head_dim + i : 2 * pr, r1 = rot && neox ? r0 + half : r0 + 1;   // rows of the matrix
     float x0 = 0.0f, x1 = 0.0f;
-#pragma unroll 8
     for (uint32_t s = 0; s < S; s++) {
       const float* row = part + ((size_t)s * kPfTokens + t) * ncols + base;
       x0 += row[r0];
