@@ -7,7 +7,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 SAN="-O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer"
 ASAN_LIB=$(g++ -print-file-name=libasan.so)
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:allocator_may_return_null=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-g++ $SAN -ffp-contract=off -fno-fast-math -pthread -o /tmp/liboracle_asan.so "$R"/oracle/quant.cpp "$R"/oracle/ops.cpp "$R"/oracle/model.cpp
+g++ $SAN -ffp-contract=off -fno-fast-math -pthread -o /tmp/liboracle_asan.so "$R"/oracle/quant.cpp "$R"/oracle/ops.cpp "$R"/oracle/model.cpp "$R"/oracle/turboquant.cpp
 g++ $SAN -I"$R"/include -o /tmp/libgguf_asan.so "$R"/llama-gguf_amd/csrc/gguf_loader.cpp "$R"/tools/sanitize/gguf_stubs.cpp
 cp "$R"/oracle/liboracle.so /tmp/liboracle_real.so
 trap 'cp /tmp/liboracle_real.so "$R"/oracle/liboracle.so; touch "$R"/oracle/liboracle.so' EXIT
