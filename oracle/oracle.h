@@ -13,6 +13,11 @@
  * fused quantized dot or for a whole forward pass, and the reference (Rust) cannot be built
  * in this image; for those, parity is pinned only by this restatement plus the
  * self-consistency identity dot_qX(blocks, x) == sum(dequantize_qX(blocks) * x).
+ * TurboQuant (turboquant.cpp): pinned by the unit tests of codebook.rs / rotation.rs / quant.rs / qjl.rs / kv_turboquant.rs /
+ * simd.rs that do not depend on the reference's RNG stream; the rotations' sign vectors and the QJL projection matrices are INPUTS
+ * (the reference draws them from rand's StdRng / rand_distr's StandardNormal, which are not restated), so the tests that depend on
+ * that stream are restated as properties over inputs drawn in the test — parity for a model run with the reference's OWN seeds is
+ * therefore pinned only up to "same signs / matrices in, same codes and scores out".
  *
  * Each function cites the reference file:line (relative to /root/reference) it follows.
  */
