@@ -513,7 +513,8 @@ hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint3
     Gm.ub1 = L.nseg > 1 ? ub[1] : Gm.n_units;
     Gm.ub2 = L.nseg > 2 ? ub[2] : Gm.n_units;
     const uint32_t groups = (Gm.n_units + kBWaves - 1) / kBWaves;
-    const bool seq = groups >= 160 || Gm.T == 1;             // enough units to fill the chip with whole rows per workgroup
+    static const uint32_t seq_min_groups = [] { const char* e = std::getenv("LGH_MVQB2_SEQ_GROUPS"); return e ? (uint32_t)std::atoi(e) : 160u; }();
+    const bool seq = groups >= seq_min_groups || Gm.T == 1;  // enough units to fill the chip with whole rows per workgroup
     Gm.nslots = seq ? 1 : Gm.T;
     const int nb_inst = B.n_seq <= 4 ? 4 : B.n_seq <= 8 ? 8 : 16;
     Gm.cb = std::max(1u, std::min(Gm.nbw, mvqb2_stage_bytes((mask & (mask - 1)) == 0, nb_inst) / (B.n_seq * (uint32_t)kXqRecord)));
