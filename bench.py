@@ -113,6 +113,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="multi-sequence decode with this many sequences per step (1..16); not the headline metric")
     ap.add_argument("--reps", type=int, default=3, help="timed repetitions of the K-step region (SURVEY.md §8d: 1 warm-up + 3, mean and min)")
     ap.add_argument("--flags", type=int, default=0, help="extra LGH_FLAG_* bits for the engine context")
+    ap.add_argument("--kv-cache-type", default="f32",
+                    help="KV cache format, the reference's --kv-cache-type strings (f32, tq2, tq3, tq2-qjl, tq3-qjl; src/config.rs:808-817) plus "
+                         "int8 / fp8e4m3 / fp8e5m2 (QuantizedKVCache's formats); not the headline metric")
     ap.add_argument("--inlib", action="store_true",
                     help="N > 1 in ONE process: the in-library pipeline (lgh_pipeline_*: peer copies + events between the stages' streams) "
                          "instead of one rank per GPU over RCCL")
@@ -176,8 +179,12 @@ def run_single(args, pkg):
     want_cpu = args.cpu_seconds > 0
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
+    kv_types = {"f32": 0, "int8": 1, "fp8e4m3": 2, "fp8e5m2": 3, "tq2": 4, "turboquant2": 4, "tq3": 5, "turboquant3": 5,
+                "tq2-qjl": 6, "turboquant2-qjl": 6, "tq3-qjl": 7, "turboquant3-qjl": 7}
+    if args.kv_cache_type.lower() not in kv_types:
+        raise SystemExit(f"bench.py: unknown --kv-cache-type {args.kv_cache_type}")
     eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct,
-                                         flags=args.flags)
+                                         flags=args.flags, kv_cache_type=kv_types[args.kv_cache_type.lower()])
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
@@ -289,7 +296,8 @@ def run_single(args, pkg):
                         "min_ms_per_step": round(1e3 * min(rep_s) / K, 4), "best_value": round(K / min(rep_s), 2),
                         "protocol": "W warm-up steps, then n repetitions of exactly K steps from the same cache state; value = K / mean"},
         "config": {"workload": f"{args.model} {args.mix} single-stream greedy decode, seq_len=1, {args.prompt}-token prompt "
-                               f"prefilled, kv_len {kv0 + 1}..{kv1}", "quant_mix": args.mix, "prompt_tokens": args.prompt,
+                               f"prefilled, kv_len {kv0 + 1}..{kv1}" + ("" if args.kv_cache_type == "f32" else f", KV cache {args.kv_cache_type}"),
+                   "quant_mix": args.mix, "prompt_tokens": args.prompt,
                    "parallelism": "single GPU", "weights": "random-init synthetic blocks (SURVEY.md §8d)"},
         "hbm_roofline": {"alg_bytes_per_token": int(step_bytes), "achieved_GBps": round(step_bytes * tok_s / 1e9, 1),
                          "peak_GBps": HBM_PEAK_GBPS, "frac": round(step_bytes * tok_s / 1e9 / HBM_PEAK_GBPS, 4),

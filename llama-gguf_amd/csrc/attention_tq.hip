@@ -13,11 +13,14 @@
 // Lloyd-Max cell for N(0, 1 / d) (codebook.rs:79-92: the number of boundaries it is >=), 2 bits (4 per byte) or 3 bits (8 per
 // 3 bytes, little-endian 24-bit groups) (codebook.rs:131-170).  CODES ARE BIT-EXACT with the reference's arithmetic: the
 // butterfly performs the same additions in the same order (tests: lgh_op_tq_compress vs the oracle).
-// Attention (kv_turboquant.rs:127-172): score_p = sum_i (H D q)_i c[K_p,i] — a strictly sequential f32 sum in the reference, and
-// here: one lane per cached position walks the 128 coordinates in order — times scale; softmax; out = sum_p w_p R^-1(c[V_p]).
-// The reference inverts the rotation per position; R^-1 is linear, so this kernel accumulates sum_p w_p c[V_p] in the rotated
-// space and the merge kernel inverts ONCE per head (rotation.rs:80-96) — same value up to f32 rounding; like the f32 attention
-// it does not apply the reference's `weight < 1e-8` skip (each skipped term is < 1e-8 of the output scale).
+// Attention (kv_turboquant.rs:127-172): score_p = sum_i (H D q)_i c[K_p,i] times scale; softmax; out = sum_p w_p R^-1(c[V_p]).
+// The reference adds a row's 128 products one after the other and inverts the rotation per position.  Here (second structure,
+// round 3: the first one walked a row's coordinates sequentially in one lane — 464 tokens/s at kv 200, 276 at kv 4000 on the bench
+// model, against 545 / 490 now and 617 / 550 with the f32 cache) a cached row is shared by D / 16 lanes, 16 coordinates each: the
+// lane's 4 (2-bit) or 6 (3-bit) code bytes are decoded to centroids in registers, the partial dot products meet by DPP, one pass
+// with an online softmax accumulates sum_p w_p c[V_p] in the ROTATED space, and the merge kernel inverts the rotation ONCE per head
+// (R^-1 is linear; rotation.rs:80-96) — the same terms in another order, equal to f32 rounding; like the f32 attention it does not
+// apply the reference's `weight < 1e-8` skip (each skipped term is < 1e-8 of the output scale).
 //
 // Launch structure = the f32 / int8 caches': (kv head x split) workgroups leave (m, l, acc) partials, a merge kernel per query
 // head combines them — plus, here, the inverse rotation and the XQ image for the output projection.  The QKV launch leaves the
@@ -76,6 +79,29 @@ __device__ __forceinline__ void tq_fwht_rows(float* buf, uint32_t rows) {
     }
   }
   __syncthreads();
+}
+
+// The same butterflies for ONE vector per wave, in registers: lane l holds elements l (and l + 64 when D = 128).  Stage `half`
+// pairs (i, i + half), i without bit `half`: new[i] = a + b, new[i + half] = a - b with a the lower element — the partner comes
+// through a cross-lane exchange, the operations and their operands are the reference's (rotation.rs:113-130): bit-identical to
+// tq_fwht_rows, without its barrier per stage.
+template <int D>
+__device__ __forceinline__ void tq_fwht_wave(float& x0, float& x1, uint32_t lane) {
+#pragma unroll
+  for (uint32_t half = 1; half < 64 && half < (uint32_t)D; half <<= 1) {
+    const bool upper = (lane & half) != 0;
+    const float p0 = __shfl_xor(x0, (int)half, 64);
+    x0 = upper ? p0 - x0 : x0 + p0;
+    if (D == 128) {
+      const float p1 = __shfl_xor(x1, (int)half, 64);
+      x1 = upper ? p1 - x1 : x1 + p1;
+    }
+  }
+  if (D == 128) {   // half = 64: the lane's own two elements
+    const float a = x0, b = x1;
+    x0 = a + b;
+    x1 = a - b;
+  }
 }
 
 // codes of the D floats at `y` (already rotated) -> row bytes, by the first D / 4 (2 bits) or D / 8 (3 bits) threads
@@ -162,14 +188,18 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
   constexpr uint32_t RB = tq_row_bytes<BITS>(D);
   constexpr uint32_t NROT = QJL ? 2 * G + 3 : G + 2;
   constexpr uint32_t XW = D / 32 + 1;                                // words of a QJL row
+  constexpr int NW = 4;                                              // waves
+  constexpr int LPR = D / 16;                                        // lanes per cached row: 16 coordinates each
+  constexpr int RPW = 64 / LPR;                                      // rows per wave-instruction
   float* rot = reinterpret_cast<float*>(smem);                       // [G + 2][D] (+ QJL: pq[G][D], res[D])
   float* pq = rot + (G + 2) * D;
   float* res = pq + G * D;
   uint8_t* newk = smem + NROT * D * 4;                               // [RB] (padded to 64)
   uint8_t* newv = newk + 64;
   uint32_t* newx = reinterpret_cast<uint32_t*>(newv + 64);           // [XW] (padded to 32 bytes)
-  float* sc = reinterpret_cast<float*>(newv + 64 + 32);              // [G][cap]
-  float* redm = sc + (size_t)G * cap;                                // [G][8]  per-wave maxima / sums
+  float* s_ml = reinterpret_cast<float*>(newv + 64 + 32);            // [NW][G][2]
+  float* s_acc = s_ml + NW * G * 2;                                  // [NW][G][D]
+  (void)cap;
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t pw;
@@ -177,134 +207,183 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
   const uint32_t pos = pw, kv_len = pw + 1;
   const float* sk = signs + (size_t)(kvh * 2) * D;
   const float* sv = sk + D;
+  uint8_t* krow0 = kq + (size_t)kvh * max_seq * RB;
+  uint8_t* vrow0 = vq + (size_t)kvh * max_seq * RB;
+  uint32_t* xrow0 = QJL ? kx + (size_t)kvh * max_seq * XW : nullptr;
+  const uint32_t sub = lane / LPR, li = lane % LPR;
+  // 16 codes of a row for this lane: bits [0, 16 * BITS) of the returned word(s)
+  auto load_codes = [&](const uint8_t* row) -> unsigned long long {
+    if (BITS == 2) return *reinterpret_cast<const uint32_t*>(row + li * 4);
+    const uint32_t off = li * 6, al = off & ~3u;                        // 6 bytes at a 2-byte aligned offset of a 48-byte row
+    const unsigned long long w = (unsigned long long)*reinterpret_cast<const uint32_t*>(row + al) |
+                                 (unsigned long long)*reinterpret_cast<const uint32_t*>(row + (al + 4 < RB ? al + 4 : al)) << 32;
+    return w >> ((off & 3u) * 8);
+  };
+  const uint32_t stride = n_splits * NW * RPW;
+  auto row_of = [&](uint32_t base) { const uint32_t p = base + sub; return p < kv_len ? p : kv_len - 1; };
+  auto fetch_mem = [&](uint32_t r, unsigned long long& kc, unsigned long long& vc, uint32_t& sgn, float& rnorm) {
+    kc = load_codes(krow0 + (size_t)r * RB);
+    vc = load_codes(vrow0 + (size_t)r * RB);
+    sgn = 0; rnorm = 0.0f;
+    if (QJL) {
+      const uint32_t* xr = xrow0 + (size_t)r * XW;
+      sgn = (xr[li >> 1] >> ((li & 1u) * 16)) & 0xFFFFu;               // sign bits of coordinates 16 li .. 16 li + 15
+      rnorm = __uint_as_float(xr[D / 32]);
+    }
+  };
+  auto fetch_lds = [&](unsigned long long& kc, unsigned long long& vc, uint32_t& sgn, float& rnorm) {   // the row this launch writes
+    kc = load_codes(newk);
+    vc = load_codes(newv);
+    sgn = 0; rnorm = 0.0f;
+    if (QJL) { sgn = (newx[li >> 1] >> ((li & 1u) * 16)) & 0xFFFFu; rnorm = __uint_as_float(newx[D / 32]); }
+  };
+  // the first rows of this wave are requested NOW, ahead of the rotations (row `pos` holds stale bytes until this launch has
+  // written it: read anyway — it lies inside the cache — and replaced from LDS below)
+  constexpr int kAhead = 2;
+  const uint32_t base0 = (sp * NW + wave) * RPW;
+  unsigned long long kk0[kAhead], vv0[kAhead];
+  uint32_t sg0[kAhead];
+  float rn0[kAhead];
+#pragma unroll
+  for (int j = 0; j < kAhead; j++) fetch_mem(row_of(base0 + j * stride), kk0[j], vv0[j], sg0[j], rn0[j]);
   // ---- D x (sign flip), then H, then 1 / sqrt(d): the G query heads with the K engine's signs, the new K row, the new V row
-  for (uint32_t e = tid; e < (G + 2) * D; e += 256) {
-    const uint32_t r = e / D, i = e % D;
-    float v;
-    if (r < G) v = q[((size_t)kvh * G + r) * D + i] * sk[i];
-    else if (r == G) v = k_new[(size_t)kvh * D + i] * sk[i];
-    else v = v_new[(size_t)kvh * D + i] * sv[i];
-    rot[e] = v;
+  // (a wave per vector, butterflies in registers: one barrier for all G + 2 vectors instead of one per stage)
+  for (uint32_t r = wave; r < (uint32_t)(G + 2); r += NW) {
+    const float* src = r < (uint32_t)G ? q + ((size_t)kvh * G + r) * D : r == (uint32_t)G ? k_new + (size_t)kvh * D : v_new + (size_t)kvh * D;
+    const float* sg = r <= (uint32_t)G ? sk : sv;
+    float x0 = src[lane] * sg[lane], x1 = 0.0f;
+    if (D == 128) x1 = src[lane + 64] * sg[lane + 64];
+    tq_fwht_wave<D>(x0, x1, lane);
+    rot[r * D + lane] = x0 * T.norm;
+    if (D == 128) rot[r * D + lane + 64] = x1 * T.norm;
   }
-  tq_fwht_rows<D>(rot, G + 2);
-  for (uint32_t e = tid; e < (G + 2) * D; e += 256) rot[e] *= T.norm;
   __syncthreads();
   tq_pack_row<D, BITS>(T, rot + G * D, newk);
   tq_pack_row<D, BITS>(T, rot + (G + 1) * D, newv);
   __syncthreads();
-  uint8_t* krow0 = kq + (size_t)kvh * max_seq * RB;
-  uint8_t* vrow0 = vq + (size_t)kvh * max_seq * RB;
   if (sp == 0 && tid < RB) { krow0[(size_t)pos * RB + tid] = newk[tid]; vrow0[(size_t)pos * RB + tid] = newv[tid]; }
-  uint32_t* xrow0 = QJL ? kx + (size_t)kvh * max_seq * XW : nullptr;
   if (QJL) {
     tq_qjl_rows<D, BITS>(T, qjl_s + (size_t)kvh * D * D, G, rot, rot + G * D, newk, res, pq, newx);
     if (sp == 0 && tid < XW) xrow0[(size_t)pos * XW + tid] = newx[tid];
   }
-  // ---- scores: position p = (it * 256 + tid) * n_splits + sp; one lane walks the D coordinates of its position in order
-  const uint32_t npos = kv_len > sp ? (kv_len - sp + n_splits - 1) / n_splits : 0;   // positions of this split
-  float mloc[G];
+  // ---- one pass over this split's positions, online softmax (the structure of the f32 cache's attn_partial_kernel): LPR lanes share
+  // a cached row, 16 coordinates each — their codes are 4 bytes (2 bits) or 6 bytes (3 bits) of the row, decoded to centroids in
+  // registers; a lane's partial dot products are summed over the row's lanes by DPP.  (The reference sums a row's 128 products one
+  // after the other, codebook.rs:228-248; this sum is the same products in another order.)  V: sum_p w_p c[V_p] in the rotated space.
+  float m[G], l[G], acc[G][16];
 #pragma unroll
-  for (int g = 0; g < G; g++) mloc[g] = -1e30f;
-  for (uint32_t j = tid; j < npos; j += 256) {
-    const uint32_t p = j * n_splits + sp;
-    uint32_t words[RB / 4];
-    const uint8_t* row = p == pos ? newk : krow0 + (size_t)p * RB;
+  for (int g = 0; g < G; g++) {
+    m[g] = -1e30f; l[g] = 0.0f;
 #pragma unroll
-    for (uint32_t w = 0; w < RB / 4; w++) words[w] = *reinterpret_cast<const uint32_t*>(row + 4 * w);
+    for (int c = 0; c < 16; c++) acc[g][c] = 0.0f;
+  }
+  auto step = [&](uint32_t base, unsigned long long kc, unsigned long long vc, uint32_t sgn, float rnorm) {
+    const bool valid = base + sub < kv_len;
+    // (8 heads per kv head: the rotated / projected queries stay in LDS — hoisted into registers beside the 128 accumulators they spill)
+    const float* rotv = rot;
+    const float* pqv = pq;
+    if (G >= 8) asm volatile("" : "+v"(rotv), "+v"(pqv));
     float s[G];
 #pragma unroll
     for (int g = 0; g < G; g++) s[g] = 0.0f;
+    float tq_[G];
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)D; i++) {
-      uint32_t idx;
-      if (BITS == 2) idx = (words[i >> 4] >> ((i & 15u) * 2)) & 3u;
-      else {
-        const uint32_t bit = (i >> 3) * 24 + (i & 7u) * 3;            // 24-bit groups, little-endian
-        const uint32_t w0 = words[bit >> 5], sh = bit & 31u;
-        idx = (sh <= 29 ? (w0 >> sh) : ((w0 >> sh) | (words[(bit >> 5) + 1] << (32 - sh)))) & 7u;
+    for (int g = 0; g < G; g++) tq_[g] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const float cv = tq_centroid<BITS>(T, (uint32_t)(kc >> (c * BITS)) & ((1u << BITS) - 1u));
+#pragma unroll
+      for (int g = 0; g < G; g++) s[g] = __builtin_fmaf(rotv[g * D + li * 16 + c], cv, s[g]);
+      if (QJL) {
+        const bool plus = (sgn >> c) & 1u;
+#pragma unroll
+        for (int g = 0; g < G; g++) { const float v = pqv[g * D + li * 16 + c]; tq_[g] += plus ? v : -v; }
       }
-      const float cv = tq_centroid<BITS>(T, idx);
-#pragma unroll
-      for (int g = 0; g < G; g++) s[g] += rot[g * D + i] * cv;        // sum += query[i] * centroid (codebook.rs:228-248)
     }
+    const float cn = QJL ? T.qjl_coeff * rnorm : 0.0f;                  // coeff * key_norm (qjl.rs:120-131)
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      if (!QJL) s[g] *= scale;
-      sc[(size_t)g * cap + j] = s[g];
-      if (!QJL) mloc[g] = fmaxf(mloc[g], s[g]);
+      float sg = QJL ? s[g] + cn * tq_[g] : s[g];                       // polar_score + correction, this lane's share
+      sg += dpp_f<0xB1>(sg);
+      sg += dpp_f<0x4E>(sg);
+      if (LPR >= 8) sg += dpp_f<0x141>(sg);
+      sg *= scale;
+      const float mn = valid ? fmaxf(m[g], sg) : m[g];
+      const float a = __expf(m[g] - mn);
+      const float pe = valid ? __expf(sg - mn) : 0.0f;
+      l[g] = __builtin_fmaf(l[g], a, pe);
+      m[g] = mn;
+      s[g] = pe;
+      tq_[g] = a;
     }
-  }
-  if (QJL) {
-    // second pass over the split's positions: score = (polar_score + inner_product_fast) * scale (quant.rs:152-166, qjl.rs:120-131,
-    // kv_turboquant.rs:146-148).  (Its own loop: fused into the loop above the compiler keeps both query images in registers.)
-    for (uint32_t j = tid; j < npos; j += 256) {
-      const uint32_t p = j * n_splits + sp;
-      const uint32_t* xr = p == pos ? newx : xrow0 + (size_t)p * XW;
-      float t[G];
 #pragma unroll
-      for (int g = 0; g < G; g++) t[g] = 0.0f;
+    for (int c = 0; c < 16; c++) {
+      const float cv = tq_centroid<BITS>(T, (uint32_t)(vc >> (c * BITS)) & ((1u << BITS) - 1u));
 #pragma unroll
-      for (uint32_t w = 0; w < (uint32_t)D / 32; w++) {
-        uint32_t bits = xr[w];
-#pragma unroll 8
-        for (uint32_t b = 0; b < 32; b++, bits >>= 1) {
-          const bool plus = bits & 1u;
+      for (int g = 0; g < G; g++) acc[g][c] = __builtin_fmaf(acc[g][c], tq_[g], cv * s[g]);
+    }
+  };
+  for (uint32_t base = base0; base < kv_len; base += kAhead * stride) {
+    unsigned long long kk[kAhead], vv[kAhead];
+    uint32_t sg[kAhead];
+    float rn[kAhead];
+    if (base == base0) {   // requested at kernel start; the row written by this launch comes from LDS
 #pragma unroll
-          for (int g = 0; g < G; g++) { const float v = pq[g * D + w * 32 + b]; t[g] += plus ? v : -v; }   // sum += values[i] * (+-1)
-        }
+      for (int j = 0; j < kAhead; j++) {
+        kk[j] = kk0[j]; vv[j] = vv0[j]; sg[j] = sg0[j]; rn[j] = rn0[j];
+        if (row_of(base + j * stride) == pos) fetch_lds(kk[j], vv[j], sg[j], rn[j]);
       }
-      const float cn = T.qjl_coeff * __uint_as_float(xr[D / 32]);      // coeff * key_norm * sum, left to right
+    } else {
 #pragma unroll
-      for (int g = 0; g < G; g++) {
-        const float sg = (sc[(size_t)g * cap + j] + cn * t[g]) * scale;
-        sc[(size_t)g * cap + j] = sg;
-        mloc[g] = fmaxf(mloc[g], sg);
+      for (int j = 0; j < kAhead; j++) {
+        const uint32_t r = row_of(base + j * stride);
+        if (r == pos) fetch_lds(kk[j], vv[j], sg[j], rn[j]);
+        else fetch_mem(r, kk[j], vv[j], sg[j], rn[j]);
       }
     }
-  }
-  // ---- the split's softmax state per head: m = max, l = sum exp(s - m)
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    const float m = wave_max(mloc[g]);
-    if (lane == 0) redm[g * 8 + wave] = m;
+    for (int j = 0; j < kAhead; j++)
+      if (base + j * stride < kv_len) step(base + j * stride, kk[j], vv[j], sg[j], rn[j]);   // wave-uniform
   }
-  __syncthreads();
-  float msplit[G], lloc[G];
+  // merge the RPW row slots of the wave (lanes with equal li hold the same coordinates)
 #pragma unroll
-  for (int g = 0; g < G; g++) {
-    msplit[g] = fmaxf(fmaxf(redm[g * 8], redm[g * 8 + 1]), fmaxf(redm[g * 8 + 2], redm[g * 8 + 3]));
-    lloc[g] = 0.0f;
-  }
-  for (uint32_t j = tid; j < npos; j += 256) {
+  for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
-      const float e = expf(sc[(size_t)g * cap + j] - msplit[g]);
-      sc[(size_t)g * cap + j] = e;
-      lloc[g] += e;
+      const float om = __shfl_xor(m[g], off, 64), ol = __shfl_xor(l[g], off, 64);
+      const float mn = fmaxf(m[g], om);
+      const float a = expf(m[g] - mn), b = expf(om - mn);
+      l[g] = l[g] * a + ol * b;
+#pragma unroll
+      for (int c = 0; c < 16; c++) acc[g][c] = acc[g][c] * a + __shfl_xor(acc[g][c], off, 64) * b;
+      m[g] = mn;
+    }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      if (li == 0) { s_ml[(wave * G + g) * 2] = m[g]; s_ml[(wave * G + g) * 2 + 1] = l[g]; }
+#pragma unroll
+      for (int c = 0; c < 16; c++) s_acc[((size_t)wave * G + g) * D + li * 16 + c] = acc[g][c];
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int g = 0; g < G; g++) {
-    const float l = wave_sum(lloc[g]);
-    if (lane == 0) redm[g * 8 + 4 + wave] = l;
-  }
-  __syncthreads();
-  // ---- sum_p w_p c[V_p] in the rotated space: thread <-> (head, coordinate), positions in ascending order
+  // merge the waves; thread t handles output elements t, t + 256, ...
   const size_t pbase = ((size_t)kvh * n_splits + sp) * G;
   for (uint32_t e = tid; e < (uint32_t)(G * D); e += 256) {
-    const uint32_t g = e / D, i = e % D;
-    float acc = 0.0f;
-    for (uint32_t j = 0; j < npos; j++) {
-      const uint32_t p = j * n_splits + sp;
-      const uint8_t* row = p == pos ? newv : vrow0 + (size_t)p * RB;
-      acc += sc[(size_t)g * cap + j] * tq_centroid<BITS>(T, tq_index<BITS>(row, i));
+    const uint32_t g = e / D, dim = e % D;
+    float mn = s_ml[g * 2];
+#pragma unroll
+    for (int w = 1; w < NW; w++) mn = fmaxf(mn, s_ml[(w * G + g) * 2]);
+    float lsum = 0.0f, a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const float f = expf(s_ml[(w * G + g) * 2] - mn);
+      lsum += s_ml[(w * G + g) * 2 + 1] * f;
+      a += s_acc[((size_t)w * G + g) * D + dim] * f;
     }
-    part_acc[(pbase + g) * D + i] = acc;
-    if (i == 0) {
-      part_ml[(pbase + g) * 2] = msplit[g];
-      part_ml[(pbase + g) * 2 + 1] = (redm[g * 8 + 4] + redm[g * 8 + 5]) + (redm[g * 8 + 6] + redm[g * 8 + 7]);
-    }
+    part_acc[(pbase + g) * D + dim] = a;
+    if (dim == 0) { part_ml[(pbase + g) * 2] = mn; part_ml[(pbase + g) * 2 + 1] = lsum; }
   }
 }
 
@@ -398,7 +477,7 @@ template <int D, int G, int BITS, bool QJL>
 static hipError_t attn_tq_go(const TqArgs& a) {
   static bool attr_set[64] = {};
   const uint32_t cap = tq_split_cap(a.max_seq, a.n_splits);
-  const size_t lds = (size_t)(QJL ? 2 * G + 3 : G + 2) * D * 4 + 128 + 32 + (size_t)G * cap * 4 + (size_t)G * 8 * 4 + 64;
+  const size_t lds = (size_t)(QJL ? 2 * G + 3 : G + 2) * D * 4 + 128 + 32 + (size_t)4 * G * 2 * 4 + (size_t)4 * G * D * 4 + 64;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS, QJL>), 160 * 1024, attr_set); e != hipSuccess) return e;
   hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS, QJL>), dim3(a.n_kv * a.n_splits), dim3(256), lds, a.st, a.q, a.kq, a.vq, a.k_new, a.v_new,
