@@ -1,22 +1,22 @@
-// matvec_batch.hip — the int8 matrix-core mat-vec for SEVERAL sequences at once (multi-sequence decode, engine.hip:
+// matvec_batch.hip — the int8 matrix-core mat-vec for SEVERAL sequences at once (multi-sequence decode, engine_batch.hip:
 // lgh_forward_multi; the reference's BatchedEngine steps its active sequences one after the other, src/engine_batched.rs:
 // 236-290, 355-400 — every sequence with its own InferenceContext / KV cache).  One launch reads every weight tile ONCE and
 // multiplies it with the XQ records of all n_seq input vectors.
 //
 // Arithmetic.  A sequence's result is bit-identical to the single-sequence kernel (matvec_mfma.hip) on the same input: the
 // same k-slices (T, blocks per slice), per slice the blocks in ascending order through the same fused operations
-// (mvq_core.h: mvq_mac_tile(unpack, load) == mvq_consume_tile), the same two shuffles and the same sum over the slices in the
-// epilogue.  Only WHO computes differs: how many tiles a workgroup owns (the partial sums of n_seq sequences must fit LDS).
+// (mvq_core.h: mvq_mac_tile(unpack, load) == mvq_consume_tile), the same two shuffles, the same sum over the slices and the same
+// epilogue (mv_epilogue.h) per sequence.  Only WHO computes differs.
 //
-// Structure.  One workgroup of 8 waves = T k-slices x G row groups as in the single-sequence kernel; a wave walks its
-// (pass, tile) pairs two at a time and, for each pair of pairs, its blocks in order — a "step" = up to two weight tiles of
-// one block.  The next step's tiles are requested at the start of a step (registers, non-temporal loads); a step unpacks its
-// tiles once (B operands + scales, mvq_unpack_tile) and then loops over the sequences: the sequence's XQ operands of that
-// block come straight from memory (L2: they were written by the previous launch) into registers, one sequence ahead, and are
-// used for both tiles.  No LDS on the way in; LDS holds the partial sums [sequence][pass][slice][row] for the epilogue.
+// Two structures.  mvqb2 (below, the default from 2 sequences on): a workgroup = 8 (row tile, pass) units x one range of blocks,
+// the sequences' records staged ONCE per workgroup in LDS and shared by its 8 waves, sequences two at a time (the pair's 8 MFMAs,
+// then the vector work while the next pair's operands load), the epilogue as a second small launch — what bounded the first
+// structure and what each change bought: profiles/r03e_batched_decode.md.  mvqb (first): the single-sequence decomposition (a
+// workgroup = the 8 k-slices of a few row tiles) with a loop over the sequences inside it and their records from L2 into a
+// register ring; kept for one sequence and for launches whose segments do not share their input vector.
 // Epilogues: store, +residual, SwiGLU pair, RoPE (every sequence at its own position) and the K / V rows into the sequence's
 // own cache slot; optional XQ image of the output for the next launch.  MoE experts are not batched (every sequence selects
-// its own experts): engine.hip runs those layers' FFN sequence by sequence through the single-sequence kernel.
+// its own experts): engine_batch.hip runs those layers' FFN sequence by sequence through the single-sequence kernel.
 #include <algorithm>
 #include <cstdlib>
 
@@ -156,21 +156,12 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb_kernel(uint32_t wbpack, uin
 #pragma unroll
     for (int s = 0; s < NB; s++) {
       if ((uint32_t)s < n_seq) {
-#ifdef LGH_MVQB_NOMAC   // experiment: memory side only
-        acc[s][0] += xr[s % kXd].xs[0] + __builtin_bit_cast(float, xr[s % kXd].a[3][3]) + t0.dd;
-        acc[s][1] += xr[s % kXd].sx[1] + t1.dd;
-#else
         mvq_mac_tile<MASK>(fmt, t0, xr[s % kXd], acc[s][0]);
         if (two) mvq_mac_tile<MASK>(fmt, t1, xr[s % kXd], acc[s][1]);
-#endif
-#ifndef LGH_MVQB_NOX    // experiment: arithmetic side only
         if ((uint32_t)(s + kXd) < n_seq) x_issue(b, s + kXd, xr[s % kXd]);
-#endif
       }
     }
-#ifndef LGH_MVQB_NOX
     if (more) x_prime(b_next);   // the next step's first sequences, ahead of its weight prefetch
-#endif
     if (b + 1 == nblk_w) {   // last block of the group's pairs: the four lane groups -> one partial sum per row and sequence
 #pragma unroll
       for (int s = 0; s < NB; s++) {
@@ -368,26 +359,16 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
         for (int g = 0; g < NB / 2; g++) {
           if ((uint32_t)(2 * g) < n_seq) {
             MacD m0, m1;
-#ifdef LGH_MVQB2_NOMFMA   // experiment: the vector-ALU side alone
-#pragma unroll
-            for (int pp = 0; pp < 4; pp++) { m0.d[pp] = xa[0].a[pp] ^ t.bw[pp]; m1.d[pp] = xa[1].a[pp] ^ t.bw[pp]; }
-#else
             mvq_mac_mfma(t, xa[0].a, m0);
             mvq_mac_mfma(t, xa[1].a, m1);
-#endif
             if ((uint32_t)(2 * g + 2) < n_seq) {
               load_a(pa0 + (2 * g + 2) * a_step, xa[0]);
               load_a(pa0 + (2 * g + 3) * a_step, xa[1]);
               load_s(px0 + (2 * g + 2) * (uint32_t)kXqRecord, xs2[(g + 1) & 1][0]);
               load_s(px0 + (2 * g + 3) * (uint32_t)kXqRecord, xs2[(g + 1) & 1][1]);
             }
-#ifdef LGH_MVQB2_NOFIN    // experiment: the matrix-core side alone
-            acc[2 * g] += __builtin_bit_cast(float, m0.d[0].x ^ m0.d[1].y ^ m0.d[2].z ^ m0.d[3].w) + xs2[g & 1][0].xs[0] + xs2[g & 1][0].sx[1];
-            acc[2 * g + 1] += __builtin_bit_cast(float, m1.d[0].x ^ m1.d[1].y ^ m1.d[2].z ^ m1.d[3].w) + xs2[g & 1][1].xs[0] + xs2[g & 1][1].sx[1];
-#else
             mvq_mac_finish<MASK>(fmt, t, m0, xs2[g & 1][0].xs, xs2[g & 1][0].sx, acc[2 * g]);
             mvq_mac_finish<MASK>(fmt, t, m1, xs2[g & 1][1].xs, xs2[g & 1][1].sx, acc[2 * g + 1]);
-#endif
           }
         }
       }
