@@ -126,32 +126,46 @@ __device__ __forceinline__ void tq_pack_row(const TqTables& T, const float* y, u
 
 // QJL side of a new K row and of `nq` rotated queries (all 256 threads; LDS in, LDS out):
 //   res = y - dequantized codes of y (quant.rs:85-89);  newx = sign bits of S res, then |res| (QjlProjector::compress, qjl.rs:36-62);
-//   pq[r] = S xq[r] (project_query, qjl.rs:100-114).  Every dot product is the reference's loop: dot += s_ij * x[j] in order, unfused.
+//   pq[r] = S xq[r] (project_query, qjl.rs:100-114).  The residual's dot products are the reference's loop (dot += s_ij * x[j] in
+//   order, unfused: the stored sign bits must be its bits); the projected queries only enter the scores and are summed in parallel.
 template <int D, int BITS>
 __device__ __forceinline__ void tq_qjl_rows(const TqTables& T, const float* __restrict__ S, uint32_t nq, const float* xq, const float* y,
                                             const uint8_t* codes, float* res, float* pq, uint32_t* newx) {
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   if (tid < D) res[tid] = y[tid] - tq_centroid<BITS>(T, tq_index<BITS>(codes, tid));
   __syncthreads();
-  for (uint32_t e = tid; e < (nq + 1) * D; e += 256) {    // a wave's 64 lanes: one row r, 64 consecutive i (D is a multiple of 64)
-    const uint32_t r = e / D, i = e % D;
-    const float* x = r < nq ? xq + r * D : res;
+  // residual row, threads [0, D): dot += s_ij * x[j] in order, unfused — the stored sign bits are the reference's bit for bit
+  if (tid < D) {
+    const uint32_t i = tid;
     const float4* srow = reinterpret_cast<const float4*>(S + (size_t)i * D);
     float dot = 0.0f;
 #pragma unroll 8
     for (uint32_t j4 = 0; j4 < (uint32_t)D / 4; j4++) {   // (8 row loads in flight: enough to cover L2, no register blow-up)
       const float4 s4 = srow[j4];
-      dot += s4.x * x[4 * j4];
-      dot += s4.y * x[4 * j4 + 1];
-      dot += s4.z * x[4 * j4 + 2];
-      dot += s4.w * x[4 * j4 + 3];
+      dot += s4.x * res[4 * j4];
+      dot += s4.y * res[4 * j4 + 1];
+      dot += s4.z * res[4 * j4 + 2];
+      dot += s4.w * res[4 * j4 + 3];
     }
-    if (r < nq) {
-      pq[r * D + i] = dot;
-    } else {
-      const unsigned long long b = __ballot(dot >= 0.0f);              // bit (i % 64) of word i / 64 (qjl.rs:58-60)
-      if (lane == 0) { newx[(i >> 6) * 2] = (uint32_t)b; newx[(i >> 6) * 2 + 1] = (uint32_t)(b >> 32); }
+    const unsigned long long bl = __ballot(dot >= 0.0f);                // bit (i % 64) of word i / 64 (qjl.rs:58-60)
+    if (lane == 0) { newx[(i >> 6) * 2] = (uint32_t)bl; newx[(i >> 6) * 2 + 1] = (uint32_t)(bl >> 32); }
+  }
+  // projected queries (only the scores use them, to rounding): four lanes share a dot product, 32 terms each, summed by DPP
+  for (uint32_t e = tid; e < nq * D * 4; e += 256) {
+    const uint32_t part = e & 3u, ri = e >> 2, r = ri / D, i = ri % D;
+    const float4* srow = reinterpret_cast<const float4*>(S + (size_t)i * D + part * (D / 4));
+    const float* x = xq + r * D + part * (D / 4);
+    float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+    for (uint32_t j4 = 0; j4 < (uint32_t)D / 16; j4 += 2) {
+      const float4 a4 = srow[j4], b4 = srow[j4 + 1];
+      d0 += a4.x * x[4 * j4] + a4.y * x[4 * j4 + 1] + a4.z * x[4 * j4 + 2] + a4.w * x[4 * j4 + 3];
+      d1 += b4.x * x[4 * j4 + 4] + b4.y * x[4 * j4 + 5] + b4.z * x[4 * j4 + 6] + b4.w * x[4 * j4 + 7];
     }
+    float dot = d0 + d1;
+    dot += dpp_f<0xB1>(dot);
+    dot += dpp_f<0x4E>(dot);
+    if (part == 0) pq[r * D + i] = dot;
   }
   if (tid == 255) {                                                    // l2_norm (qjl.rs:180-182): sequential sum of squares
     float ss = 0.0f;
