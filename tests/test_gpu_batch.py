@@ -171,3 +171,31 @@ def test_short_context_variant_of_the_single_engine_agrees_to_rounding(pkg):
     assert worst <= 1e-5, worst
     multi.close()
     single.close()
+
+
+def test_long_context_slots_use_the_long_context_attention_and_stay_bitwise(pkg):
+    """max_seq >= 2048 switches the split attention to its 8-wave variant (attention.hip), also for the multi-sequence launch: two
+    slots with prompts of 2100 and 37 tokens (batched prompt path), then 6 steps; each sequence's logits equal the single-sequence
+    engine's bit for bit, and the device-fed greedy loop equals its greedy decode."""
+    cfg, model, multi, (single,) = _engines(pkg, "test-dense-d128", "Q4_K_M", max_seq=2304)
+    multi.batch_create(2)
+    prompts = [_history(cfg, 300, 2100), _history(cfg, 301, 37)]
+    for s in range(2):
+        multi.batch_prefill(s, prompts[s][:-1])
+    toks = [p[-1] for p in prompts]
+    got = []
+    for step in range(6):
+        logits, nxt = multi.forward_multi([0, 1], toks, want_logits=True, greedy=True)
+        got.append(logits.copy())
+        toks = [int(t) for t in nxt]
+    for s in range(2):
+        single.reset()
+        single.forward_batch(prompts[s][:-1])
+        tok = prompts[s][-1]
+        for step in range(6):
+            want = single.forward(tok)
+            assert np.array_equal(got[step][s].view(np.uint32), want.view(np.uint32)), (s, step, float(np.abs(got[step][s] - want).max()))
+            tok = int(np.flatnonzero(want == want.max())[-1])
+        assert multi.batch_position(s) == len(prompts[s]) - 1 + 6
+    multi.close()
+    single.close()
