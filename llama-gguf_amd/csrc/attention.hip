@@ -26,9 +26,6 @@
 
 LGH_TL_DEFINE(attn)
 
-#ifndef LGH_DIRECT_AHEAD
-#define LGH_DIRECT_AHEAD 4
-#endif
 namespace lgh {
 
 constexpr float kNegBig = -1e30f;
@@ -121,7 +118,7 @@ __global__ void __launch_bounds__(NW * 64) attn_partial_kernel(const float* __re
   // Batches of kAhead iterations: all their K/V rows are requested before the first one is used (clamped when past the
   // end, so the loads are unconditional).  At decode lengths a workgroup has 1-3 iterations and everything is in flight
   // at once; at 4K context it has ~30, and with a single iteration ahead the kernel ran at 1 TB/s (latency-bound).
-  constexpr int kAhead = DIRECT ? LGH_DIRECT_AHEAD : 4;   // (8 measured slower for the split kernel: 604 / 518 vs 614 / 528 tokens/s at kv 272 / 4000)
+  constexpr int kAhead = 4;   // (8 measured slower: 604 / 518 vs 614 / 528 tokens/s at kv 272 / 4000)
   for (uint32_t base = (sp * NW + wave) * RPW; base < kv_len; base += kAhead * stride) {
     f32x4 kk[kAhead], vv[kAhead];
 #pragma unroll
