@@ -32,6 +32,7 @@ def _history(cfg, seq, n):
 @pytest.mark.parametrize("name,mix,B", [("test-dense", "Q4_K_M", 1), ("test-dense", "Q4_K_M", 2), ("test-dense", "Q4_K_M", 5),
                                         ("test-dense-d128", "Q4_K_M", 4), ("test-dense-d128", "Q4_K_M", 8), ("test-dense-d128", "Q4_K_M", 16),
                                         ("test-dense", "Q8_0", 3), ("test-dense", "Q5_K_M", 4), ("test-dense", "Q6_K", 7), ("test-dense", "Q4_0", 2),
+                                        ("test-dense", "Q5_K_M", 12), ("test-dense", "Q8_0", 9), ("test-dense-d128", "Q6_K", 16),
                                         ("test-moe", "Q5_K_M", 3), ("test-moe", "Q4_K_M", 16)])
 def test_every_sequence_gets_the_single_sequence_logits_bitwise(pkg, name, mix, B):
     """B sequences with different histories and RAGGED lengths, token by token through lgh_forward_multi; each sequence's logits
