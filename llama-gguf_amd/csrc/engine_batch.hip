@@ -332,7 +332,7 @@ int lgh_batch_create(lgh_ctx* c, uint32_t max_batch) {
   const size_t B = max_batch;
   // partial sums between the two launches of a multi-sequence mat-vec (matvec_batch.hip, mvqb2): per sequence either one value per
   // launch row (any matrix) or 8 slices x the rows of a matrix with fewer than 1600 row tiles
-  Bs.mv_part_floats = B * std::max<uint64_t>({(uint64_t)8 * 1600 * 16, (uint64_t)d.vocab_size + 16, (uint64_t)2 * ffn, (uint64_t)QD + 2 * d.num_kv_heads * d.head_dim});
+  Bs.mv_part_floats = B * std::max<uint64_t>({(uint64_t)8 * 1600 * 16, (uint64_t)d.vocab_size + 16, (uint64_t)2 * ffn, (uint64_t)QD + 2 * d.num_kv_heads * d.head_dim, (uint64_t)H});
   uint8_t *xq_h = nullptr, *xq_a = nullptr, *xq_f = nullptr, *xq_f2 = nullptr;
   float *ssq_h = nullptr, *ssq_a = nullptr, *ssq_f = nullptr, *ssq_f2 = nullptr;
   struct { void** p; size_t n; } bufs[] = {
