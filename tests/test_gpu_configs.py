@@ -11,6 +11,7 @@ MoE layer src/model/moe.rs:321-413):
 (Llama-3-8B Q4_K_M at full size is in test_gpu_model.py / test_gpu_prefill.py.)  Tolerances as everywhere
 (SURVEY.md §8c): logits max|d| <= 2e-3*max|logit| + 2e-3 on the exact path, 1e-2*max|logit| + 1e-2 after a batched
 (f16 GEMM) prompt pass; greedy tokens identical wherever the oracle's top-1/top-2 gap exceeds 4x the error."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -177,3 +178,70 @@ def test_llama3_70b_q4_k_m_full_size_properties_and_two_stage_split(pkg, orc):
     finally:
         for e in (eng, s0, s1):
             e.close()
+
+
+def test_full_size_llama3_8b_batched_step_and_turboquant(pkg, orc):
+    """Round-3 paths at BASELINE.json's FULL headline size (Llama-3-8B Q4_K_M, 32 layers, vocab 128256):
+    (1) a multi-sequence step gives every sequence the single-sequence engine's logits BIT FOR BIT (3 sequences, ragged histories,
+        4 steps; the device-fed greedy loop equals the single-sequence greedy decode);
+    (2) the TurboQuant-3-bit KV cache (`--kv-cache-type tq3`) against the CPU oracle with the same sign vectors: logits of a short
+        prompt and two greedy steps within the TurboQuant tolerance, greedy tokens identical where the gap allows."""
+    cfg = pkg.make_config("llama-3-8b", max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix="Q4_K_M")
+    multi = pkg.HipGpuInference.from_model(model, 64)
+    single = pkg.HipGpuInference.from_model(model, 64, attn_direct=255)
+    try:
+        multi.batch_create(4)
+        hist = [[(7919 * (s + 1) * (i + 3)) % cfg.vocab_size for i in range(3 + 2 * s)] for s in range(3)]
+        slots = [2, 0, 3]
+        for s in range(3):
+            for t in hist[s][:-1]:
+                multi.forward_multi([slots[s]], [t], want_logits=False)
+        toks = [h[-1] for h in hist]
+        got = []
+        for step in range(4):
+            logits, nxt = multi.forward_multi(slots, toks, want_logits=True, greedy=True)
+            got.append(logits.copy())
+            toks = [int(t) for t in nxt]
+        for s in range(3):
+            single.reset()
+            for t in hist[s][:-1]:
+                single.prefill_token(t)
+            tok = hist[s][-1]
+            for step in range(4):
+                want = single.forward(tok)
+                assert np.array_equal(got[step][s].view(np.uint32), want.view(np.uint32)), (s, step, float(np.abs(got[step][s] - want).max()))
+                tok = int(np.flatnonzero(want == want.max())[-1])
+    finally:
+        multi.close()
+        single.close()
+    # ---- (2) TurboQuant at full size against the oracle
+    rng = np.random.default_rng(11)
+    signs = np.where(rng.integers(0, 2, cfg.num_layers * cfg.num_kv_heads * 2 * cfg.head_dim) == 1, 1.0, -1.0).astype(np.float32)
+    ref = orc.Model(cfg.as_dict())
+    eng = None
+    try:
+        for nm, t, ne, data in model.tensors():
+            ref.add_tensor(nm, t, ne, data)
+        ref.finalize()
+        ref.set_kv_turboquant(3, signs)
+        orc.set_threads(min(16, os.cpu_count() or 1))
+        eng = pkg.HipGpuInference.from_model(model, 64, kv_cache_type=pkg.hip_backend.KV_TQ3, kv_rotation_signs=signs)
+        prompt = [i % cfg.vocab_size for i in (1, 128000, 77, 31999)]
+        for t in prompt[:-1]:
+            eng.prefill_token(t)
+        got, want = eng.forward(prompt[-1]), ref.forward(prompt)
+        for step in range(3):
+            tol = 4.0 * (2e-3 * float(np.abs(want).max()) + 2e-3)
+            err = float(np.abs(got - want).max())
+            assert err <= tol, f"TurboQuant step {step}: max|dlogit| {err:.3e} > {tol:.3e}"
+            srt = np.sort(want)
+            tok = orc.argmax_last(want)
+            if float(srt[-1] - srt[-2]) > 4 * err:
+                assert orc.argmax_last(got) == tok
+            if step < 2:
+                got, want = eng.forward(tok), ref.forward([tok])
+    finally:
+        ref.close()
+        if eng is not None:
+            eng.close()
