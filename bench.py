@@ -168,6 +168,17 @@ def cpu_baseline(pkg, model, cfg, budget_s: float):
                       f"per-call dequantization of the whole embedding table (llama.rs:288)"}
 
 
+KV_TYPES = {"f32": 0, "int8": 1, "fp8e4m3": 2, "fp8e5m2": 3, "tq2": 4, "turboquant2": 4, "tq3": 5, "turboquant3": 5,
+            "tq2-qjl": 6, "turboquant2-qjl": 6, "tq3-qjl": 7, "turboquant3-qjl": 7}
+
+
+def kv_cache_type_id(args) -> int:
+    """--kv-cache-type -> LGH_KV_* (the reference's strings, src/config.rs:808-817, plus QuantizedKVCache's formats)."""
+    if args.kv_cache_type.lower() not in KV_TYPES:
+        raise SystemExit(f"bench.py: unknown --kv-cache-type {args.kv_cache_type}")
+    return KV_TYPES[args.kv_cache_type.lower()]
+
+
 def run_single(args, pkg):
     import torch
     hb = pkg.hip_backend
@@ -179,12 +190,8 @@ def run_single(args, pkg):
     want_cpu = args.cpu_seconds > 0
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
-    kv_types = {"f32": 0, "int8": 1, "fp8e4m3": 2, "fp8e5m2": 3, "tq2": 4, "turboquant2": 4, "tq3": 5, "turboquant3": 5,
-                "tq2-qjl": 6, "turboquant2-qjl": 6, "tq3-qjl": 7, "turboquant3-qjl": 7}
-    if args.kv_cache_type.lower() not in kv_types:
-        raise SystemExit(f"bench.py: unknown --kv-cache-type {args.kv_cache_type}")
     eng = pkg.HipGpuInference.from_model(_Keep(model) if want_cpu else model, max_seq, attn_splits=args.attn_splits, attn_direct=args.attn_direct,
-                                         flags=args.flags, kv_cache_type=kv_types[args.kv_cache_type.lower()])
+                                         flags=args.flags, kv_cache_type=kv_cache_type_id(args))
     load_s = time.perf_counter() - t0
 
     prompt = prompt_tokens(args.prompt, cfg.vocab_size)
@@ -337,7 +344,7 @@ def run_batch(args, pkg):
     cfg = pkg.make_config(args.model, max_seq_len=max_seq)
     model = pkg.SynthModel(cfg, mix=args.mix)
     t0 = time.perf_counter()
-    eng = pkg.HipGpuInference.from_model(model, max_seq, attn_splits=args.attn_splits, flags=args.flags)
+    eng = pkg.HipGpuInference.from_model(model, max_seq, attn_splits=args.attn_splits, flags=args.flags, kv_cache_type=kv_cache_type_id(args))
     eng.batch_create(B)
     load_s = time.perf_counter() - t0
     slots = list(range(B))
@@ -367,7 +374,7 @@ def run_batch(args, pkg):
     step_bytes = model.step_alg_bytes(0) + B * per_seq_extra + (B - 1) * (cfg.vocab_size * 4 + kv_write)   # weights ONCE + per-sequence rows
     tok_s = B * K / elapsed
     # the single-sequence engine on the same box, same protocol, for the ratio
-    single = pkg.HipGpuInference.from_model(model, max_seq, attn_splits=args.attn_splits, flags=args.flags)
+    single = pkg.HipGpuInference.from_model(model, max_seq, attn_splits=args.attn_splits, flags=args.flags, kv_cache_type=kv_cache_type_id(args))
     single.forward_batch(prompts[0][:-1])
     w1 = single.decode_greedy(prompts[0][-1], 1 + W)
     torch.cuda.synchronize(); single.synchronize()
@@ -381,7 +388,8 @@ def run_batch(args, pkg):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL, "data": "synthetic",
         "repetitions": {"n": reps, "ms_per_step": [round(1e3 * r / K, 4) for r in rep_s]},
         "config": {"workload": f"{args.model} {args.mix}: {B} sequences, {args.prompt}-token prompts (batched prompt path), greedy decode, "
-                               f"kv_len {kv0 + 1}..{kv1}, every weight tile read once per step", "batch": B, "quant_mix": args.mix,
+                               f"kv_len {kv0 + 1}..{kv1}, every weight tile read once per step" + ("" if args.kv_cache_type == "f32" else f", KV cache {args.kv_cache_type}"),
+                   "batch": B, "quant_mix": args.mix,
                    "parallelism": "single GPU"},
         "per_sequence_tokens_per_s": round(tok_s / B, 2),
         "single_sequence_tokens_per_s_same_box": round(single_tok_s, 2), "speedup_vs_single_sequence": round(tok_s / single_tok_s, 3),

@@ -269,7 +269,10 @@ int lgh_op_tq_compress_qjl(int device, int bits, const float* x, size_t dim, con
  * + position), and one step feeds one token to each listed slot while reading every weight tile ONCE.  Every sequence's
  * logits are bit-identical to what lgh_forward returns for the same token history (same arithmetic, same summation orders).
  * Dense and MoE models whose matrices are in the matrix-core tile layouts (Q4_K / Q5_K / Q6_K / Q8_0 / Q4_0, k % 256 == 0);
- * anything else answers LGH_UNSUPPORTED.  The single-sequence entry points keep working on the context's own cache. */
+ * anything else answers LGH_UNSUPPORTED.  The slots' caches have the context's kv_cache_type: f32, or the TurboQuant formats
+ * (LGH_KV_TQ2 / TQ3 / TQ2_QJL / TQ3_QJL: per slot the packed code rows (+ QJL rows); the reference's BatchedEngine itself only
+ * ever creates f32 caches, engine_batched.rs:355-357); int8 / FP8 caches are not batched.  The single-sequence entry points keep
+ * working on the context's own cache. */
 int lgh_batch_create(lgh_ctx* ctx, uint32_t max_batch);                 /* BatchedEngineConfig::max_batch_size (engine_batched.rs:23-41) */
 int lgh_batch_reset(lgh_ctx* ctx, uint32_t slot);                       /* create_active_sequence: model.create_context (332-353); O(1) */
 size_t lgh_batch_position(lgh_ctx* ctx, uint32_t slot);                 /* ActiveSequence.ctx.position */

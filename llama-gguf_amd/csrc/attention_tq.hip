@@ -191,13 +191,18 @@ __device__ __forceinline__ void tq_qjl_rows(const TqTables& T, const float* __re
 // kx: [kv head][max_seq][D / 32 + 1] words (bits, then the norm).  V rows: codes only — the reference computes QJL bits for V rows
 // too but never reads them (kv_turboquant.rs:154-170).
 // ------------------------------------------------------------------------------------------------
-template <int D, int G, int BITS, bool QJL>
+// MULTI (multi-sequence decode, engine_batch.hip): blockIdx.y = the sequence; its position is pos_ptr[y], its caches are slot
+// slot_ptr[y] of kq / vq / kx (ms.code_stride bytes / ms.x_stride words apart), its query, staging rows and partials follow at the
+// strides in `ms`.  Same arithmetic, same order: a sequence's partials are the single-sequence launch's bit for bit.
+struct TqMulti { const int* slot; uint64_t code_stride, x_stride; uint32_t kv_stride; };   // kv_stride: floats between two sequences' (K row, V row) staging
+
+template <int D, int G, int BITS, bool QJL, bool MULTI>
 __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __restrict__ q, uint8_t* __restrict__ kq, uint8_t* __restrict__ vq,
                                                               const float* __restrict__ k_new, const float* __restrict__ v_new,
                                                               const float* __restrict__ signs, const TqTables T, uint32_t max_seq, float scale,
                                                               const int* pos_ptr, uint32_t n_splits, uint32_t cap,
                                                               float* __restrict__ part_ml, float* __restrict__ part_acc,
-                                                              const float* __restrict__ qjl_s, uint32_t* __restrict__ kx) {
+                                                              const float* __restrict__ qjl_s, uint32_t* __restrict__ kx, const TqMulti ms) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr uint32_t RB = tq_row_bytes<BITS>(D);
   constexpr uint32_t NROT = QJL ? 2 * G + 3 : G + 2;
@@ -217,7 +222,21 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
   const uint32_t kvh = blockIdx.x / n_splits, sp = blockIdx.x % n_splits;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   uint32_t pw;
-  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
+  if (MULTI) {
+    const uint32_t sq = blockIdx.y;
+    uint32_t sl;
+    asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(pw), "=&s"(sl) : "s"(pos_ptr + sq), "s"(ms.slot + sq) : "memory");
+    q += (size_t)sq * (gridDim.x / n_splits) * G * D;
+    k_new += (size_t)sq * ms.kv_stride;
+    v_new += (size_t)sq * ms.kv_stride;
+    kq += (size_t)sl * ms.code_stride;
+    vq += (size_t)sl * ms.code_stride;
+    if (QJL) kx += (size_t)sl * ms.x_stride;
+    part_ml += (size_t)sq * gridDim.x * G * 2;
+    part_acc += (size_t)sq * gridDim.x * G * D;
+  } else {
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pw) : "s"(pos_ptr) : "memory");
+  }
   const uint32_t pos = pw, kv_len = pw + 1;
   const float* sk = signs + (size_t)(kvh * 2) * D;
   const float* sv = sk + D;
@@ -402,10 +421,19 @@ __global__ void __launch_bounds__(256) attn_tq_partial_kernel(const float* __res
 }
 
 // merge of the splits (as attn_combine_kernel) + the inverse rotation (rotation.rs:80-96): out = signs * (1 / d) * H (sqrt(d) * o)
-template <int D>
+// MULTI: blockIdx.y = the sequence (partials of gridDim.x heads per sequence; outputs n_heads * D floats / xq_stride bytes apart)
+template <int D, bool MULTI>
 __global__ void __launch_bounds__(D) attn_tq_combine_kernel(const float* __restrict__ part_ml, const float* __restrict__ part_acc,
                                                             const float* __restrict__ signs, const TqTables T, uint32_t g_per_kv,
-                                                            uint32_t n_splits, float* __restrict__ out, uint8_t* __restrict__ xq_out) {
+                                                            uint32_t n_splits, float* __restrict__ out, uint8_t* __restrict__ xq_out,
+                                                            uint32_t xq_stride) {
+  if (MULTI) {
+    const size_t per_seq = (size_t)gridDim.x * n_splits;   // (head, split) partials of one sequence
+    part_ml += (size_t)blockIdx.y * per_seq * 2;
+    part_acc += (size_t)blockIdx.y * per_seq * D;
+    out += (size_t)blockIdx.y * gridDim.x * D;
+    if (xq_out) xq_out += (size_t)blockIdx.y * xq_stride;
+  }
   __shared__ float s_f[64];
   __shared__ float s_linv;
   __shared__ float buf[D];
@@ -485,18 +513,37 @@ uint32_t tq_split_cap(uint32_t max_seq, uint32_t n_splits) { return (max_seq + n
 struct TqArgs {
   const float* q; uint8_t *kq, *vq; const float *k_new, *v_new, *signs; uint32_t n_kv, max_seq; float scale; const int* pos; uint32_t n_splits;
   float *part_ml, *part_acc; const float* qjl_s; uint32_t* kx; hipStream_t st;
+  uint32_t n_seq; TqMulti ms;   // n_seq 0: the single-sequence launch
 };
 
 template <int D, int G, int BITS, bool QJL>
 static hipError_t attn_tq_go(const TqArgs& a) {
-  static bool attr_set[64] = {};
+  static bool attr_set[2][64] = {};
   const uint32_t cap = tq_split_cap(a.max_seq, a.n_splits);
   const size_t lds = (size_t)(QJL ? 2 * G + 3 : G + 2) * D * 4 + 128 + 32 + (size_t)4 * G * 2 * 4 + (size_t)4 * G * D * 4 + 64;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS, QJL>), 160 * 1024, attr_set); e != hipSuccess) return e;
-  hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS, QJL>), dim3(a.n_kv * a.n_splits), dim3(256), lds, a.st, a.q, a.kq, a.vq, a.k_new, a.v_new,
-                     a.signs, tq_tables(D, BITS), a.max_seq, a.scale, a.pos, a.n_splits, cap, a.part_ml, a.part_acc, a.qjl_s, a.kx);
+  if (a.n_seq) {
+    if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS, QJL, true>), 160 * 1024, attr_set[1]); e != hipSuccess) return e;
+    hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS, QJL, true>), dim3(a.n_kv * a.n_splits, a.n_seq), dim3(256), lds, a.st, a.q, a.kq, a.vq, a.k_new,
+                       a.v_new, a.signs, tq_tables(D, BITS), a.max_seq, a.scale, a.pos, a.n_splits, cap, a.part_ml, a.part_acc, a.qjl_s, a.kx, a.ms);
+  } else {
+    if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&attn_tq_partial_kernel<D, G, BITS, QJL, false>), 160 * 1024, attr_set[0]); e != hipSuccess) return e;
+    hipLaunchKernelGGL((attn_tq_partial_kernel<D, G, BITS, QJL, false>), dim3(a.n_kv * a.n_splits), dim3(256), lds, a.st, a.q, a.kq, a.vq, a.k_new, a.v_new,
+                       a.signs, tq_tables(D, BITS), a.max_seq, a.scale, a.pos, a.n_splits, cap, a.part_ml, a.part_acc, a.qjl_s, a.kx, a.ms);
+  }
   return hipGetLastError();
+}
+
+static hipError_t attn_tq_dispatch(int bits, uint32_t head_dim, uint32_t g, const TqArgs& a) {
+#define LGH_TQ_CASE(DD, GG)                                                                              \
+  if (head_dim == DD && g == GG) {                                                                       \
+    if (a.qjl_s) return bits == 2 ? attn_tq_go<DD, GG, 2, true>(a) : attn_tq_go<DD, GG, 3, true>(a);     \
+    return bits == 2 ? attn_tq_go<DD, GG, 2, false>(a) : attn_tq_go<DD, GG, 3, false>(a);                \
+  }
+  LGH_TQ_CASE(128, 1) LGH_TQ_CASE(128, 2) LGH_TQ_CASE(128, 4) LGH_TQ_CASE(128, 8)
+  LGH_TQ_CASE(64, 1) LGH_TQ_CASE(64, 2) LGH_TQ_CASE(64, 4) LGH_TQ_CASE(64, 8)
+#undef LGH_TQ_CASE
+  return hipErrorInvalidValue;
 }
 
 // bits 2 / 3; signs: this layer's [n_kv][2][head_dim]; qjl_s (TurboQuantProd; NULL = TurboQuantMSE): this layer's [n_kv][head_dim][head_dim],
@@ -506,28 +553,38 @@ hipError_t attn_tq_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, co
                           float* part_ml, float* part_acc, hipStream_t st, const float* qjl_s, uint32_t* kx) {
   if (n_kv == 0 || n_heads % n_kv || !pos || (bits != 2 && bits != 3) || n_splits == 0 || n_splits > 32 || (qjl_s != nullptr) != (kx != nullptr))
     return hipErrorInvalidValue;
-  const uint32_t g = n_heads / n_kv;
-  const TqArgs a{q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, qjl_s, kx, st};
-#define LGH_TQ_CASE(DD, GG)                                                                              \
-  if (head_dim == DD && g == GG) {                                                                       \
-    if (qjl_s) return bits == 2 ? attn_tq_go<DD, GG, 2, true>(a) : attn_tq_go<DD, GG, 3, true>(a);       \
-    return bits == 2 ? attn_tq_go<DD, GG, 2, false>(a) : attn_tq_go<DD, GG, 3, false>(a);                \
-  }
-  LGH_TQ_CASE(128, 1) LGH_TQ_CASE(128, 2) LGH_TQ_CASE(128, 4) LGH_TQ_CASE(128, 8)
-  LGH_TQ_CASE(64, 1) LGH_TQ_CASE(64, 2) LGH_TQ_CASE(64, 4) LGH_TQ_CASE(64, 8)
-#undef LGH_TQ_CASE
-  return hipErrorInvalidValue;
+  const TqArgs a{q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, qjl_s, kx, st, 0, TqMulti{}};
+  return attn_tq_dispatch(bits, head_dim, n_heads / n_kv, a);
 }
 
+// the same for n_seq sequences (grid y): positions pos[s], cache slots slot[s] (code_stride bytes / x_stride words between slots),
+// queries n_heads * head_dim floats apart, the staging (K row, V row) pairs kv_stride floats apart
+hipError_t attn_tq_multi_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs,
+                                uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, const int* slot,
+                                uint64_t code_stride, uint64_t x_stride, uint32_t kv_stride, uint32_t n_seq, uint32_t n_splits, float* part_ml,
+                                float* part_acc, hipStream_t st, const float* qjl_s, uint32_t* kx) {
+  if (n_kv == 0 || n_heads % n_kv || !pos || !slot || n_seq == 0 || (bits != 2 && bits != 3) || n_splits == 0 || n_splits > 32 ||
+      (qjl_s != nullptr) != (kx != nullptr))
+    return hipErrorInvalidValue;
+  const TqArgs a{q, kq, vq, k_new, v_new, signs, n_kv, max_seq, scale, pos, n_splits, part_ml, part_acc, qjl_s, kx, st, n_seq,
+                 TqMulti{slot, code_stride, x_stride, kv_stride}};
+  return attn_tq_dispatch(bits, head_dim, n_heads / n_kv, a);
+}
+
+// n_seq 0: single sequence; otherwise grid y = sequences, XQ images xq_stride bytes apart
 hipError_t attn_tq_combine_launch(int bits, const float* part_ml, const float* part_acc, const float* signs, uint32_t n_heads, uint32_t n_kv,
-                                  uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st) {
+                                  uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st, uint32_t n_seq,
+                                  uint32_t xq_stride) {
   if (n_kv == 0 || n_heads % n_kv || n_splits > 32 || (head_dim != 64 && head_dim != 128)) return hipErrorInvalidValue;
-  if (head_dim == 128)
-    hipLaunchKernelGGL(attn_tq_combine_kernel<128>, dim3(n_heads), dim3(128), 0, st, part_ml, part_acc, signs, tq_tables(128, bits), n_heads / n_kv,
-                       n_splits, out, xq_out);
-  else
-    hipLaunchKernelGGL(attn_tq_combine_kernel<64>, dim3(n_heads), dim3(64), 0, st, part_ml, part_acc, signs, tq_tables(64, bits), n_heads / n_kv,
-                       n_splits, out, xq_out);
+  const TqTables T = tq_tables(head_dim, bits);
+  const uint32_t gk = n_heads / n_kv;
+  if (n_seq) {
+    if (head_dim == 128) hipLaunchKernelGGL((attn_tq_combine_kernel<128, true>), dim3(n_heads, n_seq), dim3(128), 0, st, part_ml, part_acc, signs, T, gk, n_splits, out, xq_out, xq_stride);
+    else hipLaunchKernelGGL((attn_tq_combine_kernel<64, true>), dim3(n_heads, n_seq), dim3(64), 0, st, part_ml, part_acc, signs, T, gk, n_splits, out, xq_out, xq_stride);
+  } else {
+    if (head_dim == 128) hipLaunchKernelGGL((attn_tq_combine_kernel<128, false>), dim3(n_heads), dim3(128), 0, st, part_ml, part_acc, signs, T, gk, n_splits, out, xq_out, 0u);
+    else hipLaunchKernelGGL((attn_tq_combine_kernel<64, false>), dim3(n_heads), dim3(64), 0, st, part_ml, part_acc, signs, T, gk, n_splits, out, xq_out, 0u);
+  }
   return hipGetLastError();
 }
 

@@ -247,7 +247,12 @@ hipError_t attn_tq_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, co
                           uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, uint32_t n_splits,
                           float* part_ml, float* part_acc, hipStream_t st, const float* qjl_s = nullptr, uint32_t* kx = nullptr);
 hipError_t attn_tq_combine_launch(int bits, const float* part_ml, const float* part_acc, const float* signs, uint32_t n_heads, uint32_t n_kv,
-                                  uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st);
+                                  uint32_t head_dim, uint32_t n_splits, float* out, uint8_t* xq_out, hipStream_t st, uint32_t n_seq = 0,
+                                  uint32_t xq_stride = 0);
+hipError_t attn_tq_multi_launch(int bits, const float* q, uint8_t* kq, uint8_t* vq, const float* k_new, const float* v_new, const float* signs,
+                                uint32_t n_heads, uint32_t n_kv, uint32_t head_dim, uint32_t max_seq, float scale, const int* pos, const int* slot,
+                                uint64_t code_stride, uint64_t x_stride, uint32_t kv_stride, uint32_t n_seq, uint32_t n_splits, float* part_ml,
+                                float* part_acc, hipStream_t st, const float* qjl_s = nullptr, uint32_t* kx = nullptr);
 hipError_t tq_compress_launch(int bits, const float* x, uint32_t dim, const float* signs, uint8_t* out, hipStream_t st, const float* qjl_s = nullptr,
                               uint32_t* qjl_out = nullptr);
 uint32_t tq_row_bytes_host(int bits, uint32_t d);

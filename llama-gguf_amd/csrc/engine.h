@@ -62,6 +62,13 @@ struct BatchScratch {
   int *d_tokens = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_log = nullptr;   // the step's control words (device), the greedy token log
   int* h_ctl = nullptr;                               // pinned staging of the control words
   std::vector<float*> kcache, vcache;                 // per layer: [slot][kv_head][max_seq][head_dim]
+  // TurboQuant caches (kv_cache_type LGH_KV_TQ*): per layer the slots' code rows [slot][kv_head][max_seq][row bytes] (K, V) and, with
+  // QJL, the K rows' sign bits + norms [slot][kv_head][max_seq][head_dim / 32 + 1]; kv_tmp = the step's rotated K / V rows, f32,
+  // [sequence][K row | V row]
+  std::vector<uint8_t*> kq, vq;
+  std::vector<uint32_t*> kx;
+  float* kv_tmp = nullptr;
+  uint64_t code_stride = 0, x_stride = 0;             // bytes / words between two slots
   std::vector<size_t> pos;                            // per slot: tokens in its cache
   hipGraphExec_t graph[kMaxBatch + 1][2] = {};        // [n_seq][0 logits only, 1 + arg-max fed back]
 };
@@ -141,6 +148,9 @@ struct SegSpec {
 // the vectors the FFN half of a layer works on (one sequence's)
 struct FfnView { float* hidden; float* act; float* act2; float* xnorm; int* moe_sel; float* moe_w; };
 
+static inline bool kv_is_tq(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ3 || t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
+static inline bool kv_is_qjl(uint32_t t) { return t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
+static inline int kv_tq_bits(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ2_QJL ? 2 : 3; }
 int fail(lgh_ctx* c, int status, const std::string& msg);
 int build_mv_group(lgh_ctx* c, const SegSpec* specs, int nseg, const float* norm_w, uint32_t k, bool mfma, lgh::MvLaunch& L, uint32_t& wg,
                    uint32_t& threads, uint64_t& alg, uint32_t tile_cap);

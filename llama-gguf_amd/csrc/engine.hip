@@ -64,9 +64,6 @@ static void dev_free_tracked(lgh_ctx* c, void* p) {
 // otherwise.  Measured on Llama-3-8B Q4_K_M: 640 vs 618 tokens/s at kv <= 64, equal at kv 69..128, 581 vs 614 at kv
 // 137..272 — one workgroup per kv head fetches that head's whole K/V (1 KB per row) through ONE CU's memory path.
 constexpr uint32_t kDirectAttnDefaultKv = 64;
-static inline bool kv_is_tq(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ3 || t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
-static inline bool kv_is_qjl(uint32_t t) { return t == LGH_KV_TQ2_QJL || t == LGH_KV_TQ3_QJL; }
-static inline int kv_tq_bits(uint32_t t) { return t == LGH_KV_TQ2 || t == LGH_KV_TQ2_QJL ? 2 : 3; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------------

@@ -113,7 +113,7 @@ bool batch_weights_ok(const lgh_ctx* c, std::string& why) {
   if (d.hidden_size % 256 || (d.num_heads * d.head_dim) % 256) { why = "hidden size and heads x head_dim must be multiples of 256"; return false; }
   if (d.use_neox_rope) { why = "NeoX RoPE is not fused into the QKV launch"; return false; }
   if (!attn_shape_has_fast_kernel(d.head_dim, d.num_heads / d.num_kv_heads)) { why = "attention shape outside the split kernels"; return false; }
-  if (d.flags & LGH_FLAG_KV_INT8) { why = "byte KV caches are not batched"; return false; }
+  if ((d.flags & LGH_FLAG_KV_INT8) && !kv_is_tq(d.kv_cache_type)) { why = "the int8 / FP8 KV caches are not batched (f32 and TurboQuant are)"; return false; }
   if (!(c->first && c->last)) { why = "pipeline stages are not batched"; return false; }
   for (uint32_t i = c->l0; i < c->l1; i++) {
     const LayerW& L = c->layers[i];
@@ -158,11 +158,14 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
     const float* next_nw = li + 1 < c->l1 ? c->layers[li + 1].attn_norm : c->output_norm;
     // ---- Q, K, V (+ RoPE at every sequence's own position, K / V rows into its own cache slot)
     {
+      const bool tq = kv_is_tq(d.kv_cache_type);
+      const uint32_t KD = d.num_kv_heads * d.head_dim;
       SegSpec sp[3];
       sp[0].W[0] = &Lw.wq; sp[0].x[0] = Bs.hidden; sp[0].epi = EPI_ROPE_Q; sp[0].out = Bs.q; sp[0].bias = Lw.bq;
-      sp[1].W[0] = &Lw.wk; sp[1].x[0] = Bs.hidden; sp[1].epi = EPI_ROPE_K; sp[1].out = Bs.kcache[li]; sp[1].bias = Lw.bk;
-      sp[2].W[0] = &Lw.wv; sp[2].x[0] = Bs.hidden; sp[2].epi = EPI_V_CACHE; sp[2].out = Bs.vcache[li]; sp[2].bias = Lw.bv;
-      const uint32_t os[3] = {QD, 0, 0}, rs[3] = {0, 0, 0}, xk[3] = {0, 0, 0};
+      // (TurboQuant: the rotated K row and the V row stay f32 in a staging vector per sequence; the attention launch compresses them)
+      sp[1].W[0] = &Lw.wk; sp[1].x[0] = Bs.hidden; sp[1].epi = tq ? EPI_ROPE_Q : EPI_ROPE_K; sp[1].out = tq ? Bs.kv_tmp : Bs.kcache[li]; sp[1].bias = Lw.bk;
+      sp[2].W[0] = &Lw.wv; sp[2].x[0] = Bs.hidden; sp[2].epi = tq ? EPI_STORE : EPI_V_CACHE; sp[2].out = tq ? Bs.kv_tmp + KD : Bs.vcache[li]; sp[2].bias = Lw.bv;
+      const uint32_t os[3] = {QD, tq ? 2 * KD : 0, tq ? 2 * KD : 0}, rs[3] = {0, 0, 0}, xk[3] = {0, 0, 0};
       // (the three matrices may come in formats without a common instantiation: one launch each then, as launch_mv does)
       bool q4 = false, q5 = false, other = false, uniform = true;
       for (int s = 0; s < 3; s++) {
@@ -178,6 +181,28 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
       }
     }
     // ---- attention_cached per sequence (ops.rs:1479-1537): split + merge, the sequence as the grid's second dimension
+    if (kv_is_tq(d.kv_cache_type)) {
+      // TurboQuantKVCache (kv_turboquant.rs) per sequence: write_kv + attention over the slot's codes; the merge inverts the V rotation
+      const int bits = kv_tq_bits(d.kv_cache_type);
+      const bool qjl = kv_is_qjl(d.kv_cache_type);
+      const uint32_t KD = d.num_kv_heads * d.head_dim;
+      const float* signs = c->tq_signs + (size_t)(li - c->l0) * d.num_kv_heads * 2 * d.head_dim;
+      const float* qjl_s = qjl ? c->tq_qjl + (size_t)(li - c->l0) * d.num_kv_heads * d.head_dim * d.head_dim : nullptr;
+      if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, 0, [&] {
+             return attn_tq_multi_launch(bits, Bs.q, Bs.kq[li], Bs.vq[li], Bs.kv_tmp, Bs.kv_tmp + KD, signs, d.num_heads, d.num_kv_heads, d.head_dim,
+                                         d.max_seq_len, scale, Bs.d_pos, Bs.d_slot, Bs.code_stride, Bs.x_stride, 2 * KD, n_seq, c->n_splits, Bs.part_ml,
+                                         Bs.part_acc, c->stream, qjl_s, qjl ? Bs.kx[li] : nullptr);
+           })))
+        return rc;
+      XqBuf* qa = view_of(c, Bs.attn_out);
+      if ((rc = run_k(c, LGH_K_ATTN_COMBINE, LGH_SYM_ATTN_COMBINE, 0, [&] {
+             return attn_tq_combine_launch(bits, Bs.part_ml, Bs.part_acc, signs, d.num_heads, d.num_kv_heads, d.head_dim, c->n_splits, Bs.attn_out, qa->xq,
+                                           c->stream, n_seq, (uint32_t)xq_stride_of(QD));
+           })))
+        return rc;
+      for (uint32_t s = 0; s < n_seq; s++)
+        if (XqBuf* q = view_of(c, Bs.attn_out + (size_t)s * QD)) { q->fresh = true; q->tag = nullptr; }
+    } else {
     if ((rc = run_k(c, LGH_K_ATTN, LGH_SYM_ATTN, 0, [&] {
            return attn_multi_launch(Bs.q, Bs.kcache[li], Bs.vcache[li], d.num_heads, d.num_kv_heads, d.head_dim, d.max_seq_len, scale, Bs.d_pos, Bs.d_slot,
                                     Bs.cache_stride, n_seq, c->n_splits, Bs.part_ml, Bs.part_acc, c->stream);
@@ -192,6 +217,7 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
         return rc;
       for (uint32_t s = 0; s < n_seq; s++)
         if (XqBuf* q = view_of(c, Bs.attn_out + (size_t)s * QD)) { q->fresh = true; q->tag = nullptr; }
+    }
     }
     // ---- h = x + wo(attn)
     {
@@ -355,7 +381,29 @@ int lgh_batch_create(lgh_ctx* c, uint32_t max_batch) {
   }
   Bs.kcache.assign(d.num_layers, nullptr);
   Bs.vcache.assign(d.num_layers, nullptr);
-  for (uint32_t i = c->l0; i < c->l1; i++) {   // per layer K / V of every slot: [slot][kv_head][max_seq][head_dim] f32
+  Bs.kq.assign(d.num_layers, nullptr);
+  Bs.vq.assign(d.num_layers, nullptr);
+  Bs.kx.assign(d.num_layers, nullptr);
+  if (kv_is_tq(d.kv_cache_type)) {   // TurboQuantKVCache::new per slot (kv_turboquant.rs:36-86): packed codes (+ QJL rows of K)
+    const size_t rows = (size_t)d.num_kv_heads * d.max_seq_len;
+    Bs.code_stride = rows * tq_row_bytes_host(kv_tq_bits(d.kv_cache_type), d.head_dim);
+    Bs.x_stride = rows * (d.head_dim / 32 + 1);
+    if ((rc = dev_alloc(c, (void**)&Bs.kv_tmp, B * 2 * d.num_kv_heads * d.head_dim * 4))) return rc;
+    for (uint32_t i = c->l0; i < c->l1; i++) {
+      const size_t n = B * Bs.code_stride;
+      if ((rc = dev_alloc(c, (void**)&Bs.kq[i], n)) || (rc = dev_alloc(c, (void**)&Bs.vq[i], n))) return rc;
+      HIP_TRYB(c, LGH_OPERATION_FAILED, hipMemsetAsync(Bs.kq[i], 0, n, c->stream));
+      HIP_TRYB(c, LGH_OPERATION_FAILED, hipMemsetAsync(Bs.vq[i], 0, n, c->stream));
+      c->stats.kv_bytes += 2 * n;
+      if (kv_is_qjl(d.kv_cache_type)) {
+        const size_t nx = B * Bs.x_stride * 4;
+        if ((rc = dev_alloc(c, (void**)&Bs.kx[i], nx))) return rc;
+        HIP_TRYB(c, LGH_OPERATION_FAILED, hipMemsetAsync(Bs.kx[i], 0, nx, c->stream));
+        c->stats.kv_bytes += nx;
+      }
+    }
+  }
+  for (uint32_t i = c->l0; i < c->l1 && !kv_is_tq(d.kv_cache_type); i++) {   // per layer K / V of every slot: [slot][kv_head][max_seq][head_dim] f32
     const size_t n = B * Bs.cache_stride * 4;
     if ((rc = dev_alloc(c, (void**)&Bs.kcache[i], n)) || (rc = dev_alloc(c, (void**)&Bs.vcache[i], n))) return rc;
     HIP_TRYB(c, LGH_OPERATION_FAILED, hipMemsetAsync(Bs.kcache[i], 0, n, c->stream));

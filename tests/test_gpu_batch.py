@@ -200,3 +200,50 @@ def test_long_context_slots_use_the_long_context_attention_and_stay_bitwise(pkg)
         assert multi.batch_position(s) == len(prompts[s]) - 1 + 6
     multi.close()
     single.close()
+
+
+@pytest.mark.parametrize("name,mix,B,kv", [("test-dense-d128", "Q4_K_M", 3, "tq3"), ("test-dense", "Q4_K_M", 5, "tq2"),
+                                           ("test-dense-d128", "Q4_K_M", 4, "tq2-qjl"), ("test-moe", "Q5_K_M", 2, "tq3-qjl")])
+def test_turboquant_slots_bitwise(pkg, name, mix, B, kv):
+    """Multi-sequence decode over TurboQuant KV caches (kv_cache_type LGH_KV_TQ*; the reference's BatchedEngine only ever creates f32
+    caches, engine_batched.rs:355-357 -> model.create_context): every slot holds its own code rows (+ QJL rows), the step's rotated
+    K / V rows are compressed by the attention launch of their sequence; each sequence's logits equal the single-sequence TurboQuant
+    engine's BIT FOR BIT (same kernels, the sequence as the grid's second dimension), prompts fed token by token."""
+    hb = pkg.hip_backend
+    kvt = {"tq2": hb.KV_TQ2, "tq3": hb.KV_TQ3, "tq2-qjl": hb.KV_TQ2_QJL, "tq3-qjl": hb.KV_TQ3_QJL}[kv]
+    cfg = pkg.make_config(name, max_seq_len=64)
+    model = pkg.SynthModel(cfg, mix=mix)
+    rng = np.random.default_rng(23)
+    signs = np.where(rng.integers(0, 2, cfg.num_layers * cfg.num_kv_heads * 2 * cfg.head_dim) == 1, 1.0, -1.0).astype(np.float32)
+    qjl = rng.standard_normal(cfg.num_layers * cfg.num_kv_heads * cfg.head_dim * cfg.head_dim).astype(np.float32) if "qjl" in kv else None
+    multi = pkg.HipGpuInference.from_model(model, 64, kv_cache_type=kvt, kv_rotation_signs=signs, kv_qjl_matrices=qjl)
+    single = pkg.HipGpuInference.from_model(model, 64, kv_cache_type=kvt, kv_rotation_signs=signs, kv_qjl_matrices=qjl)
+    try:
+        multi.batch_create(B)
+        lens = [4 + (3 * s) % 7 for s in range(B)]
+        hist = [_history(cfg, 500 + s, lens[s]) for s in range(B)]
+        for s in range(B):
+            multi.batch_prefill(s, hist[s][:-1])                           # (token by token: no batched prompt path over a code cache)
+            assert multi.batch_position(s) == lens[s] - 1
+        toks = [h[-1] for h in hist]
+        got = []
+        for step in range(5):
+            logits, nxt = multi.forward_multi(list(range(B)), toks, want_logits=True, greedy=True)
+            got.append(logits.copy())
+            toks = [int(t) for t in nxt]
+        for s in range(B):
+            single.reset()
+            for t in hist[s][:-1]:
+                single.prefill_token(t)
+            tok = hist[s][-1]
+            for step in range(5):
+                want = single.forward(tok)
+                assert np.array_equal(got[step][s].view(np.uint32), want.view(np.uint32)), (kv, s, step, float(np.abs(got[step][s] - want).max()))
+                tok = int(np.flatnonzero(want == want.max())[-1])
+        f32 = pkg.HipGpuInference.from_model(model, 64)
+        f32.batch_create(B)
+        assert multi.stats()["kv_bytes"] < f32.stats()["kv_bytes"] // 4       # the slots' caches are the compressed ones
+        f32.close()
+    finally:
+        multi.close()
+        single.close()
