@@ -272,7 +272,8 @@ int lgh_op_tq_compress_qjl(int device, int bits, const float* x, size_t dim, con
  * anything else answers LGH_UNSUPPORTED.  The slots' caches have the context's kv_cache_type: f32, or the TurboQuant formats
  * (LGH_KV_TQ2 / TQ3 / TQ2_QJL / TQ3_QJL: per slot the packed code rows (+ QJL rows); the reference's BatchedEngine itself only
  * ever creates f32 caches, engine_batched.rs:355-357); int8 / FP8 caches are not batched.  The single-sequence entry points keep
- * working on the context's own cache. */
+ * working on the context's own cache.  (A serving context is better created with 8 attention splits — flags bits 8..15 — than with
+ * the single-sequence default: the split count also sizes the multi-sequence attention launch, profiles/r03e_batched_decode.md.) */
 int lgh_batch_create(lgh_ctx* ctx, uint32_t max_batch);                 /* BatchedEngineConfig::max_batch_size (engine_batched.rs:23-41) */
 int lgh_batch_reset(lgh_ctx* ctx, uint32_t slot);                       /* create_active_sequence: model.create_context (332-353); O(1) */
 size_t lgh_batch_position(lgh_ctx* ctx, uint32_t slot);                 /* ActiveSequence.ctx.position */
