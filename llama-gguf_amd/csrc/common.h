@@ -161,6 +161,12 @@ struct MvBatch {
   uint32_t ssq_out_stride[3];
   float* part;                // mvqb2: partial sums [slot][sequence][unit * 16 + row] between the two launches of an op
   uint64_t part_floats;
+  // Indirect entries (MoE layers of a multi-sequence step, one launch per expert): the launch works on *ind_cnt <= n_seq entries;
+  // entry j stands for the (sequence, top-k slot) pair v = ind_idx[j]: its OUTPUT vectors are the v-th at the strides above, its
+  // INPUT vector / sum-of-squares partials the (v / ind_div)-th.  ind_cnt == NULL: entry j = sequence j (everything else).
+  const int* ind_cnt;
+  const int* ind_idx;
+  uint32_t ind_div;
 };
 
 // launch-uniform geometry of one int8-MFMA launch as the kernel takes it (mvq_pack)
@@ -226,6 +232,9 @@ hipError_t argmax_launch(const float* logits, uint32_t n, float* part_val, int* 
                          hipStream_t st);
 hipError_t advance_launch(int* state, hipStream_t st);
 hipError_t copy_words_launch(void* dst, const void* src, uint32_t n_words, hipStream_t st);
+hipError_t moe_group_launch(const int* sel, uint32_t n_seq, uint32_t top_k, uint32_t n_experts, int* cnt, int* idx, uint32_t idx_stride, hipStream_t st);
+hipError_t moe_combine_launch(const float* tmp, const float* moe_w, uint32_t top_k, float* hidden, uint32_t H, uint32_t n_seq, const float* nw,
+                              uint8_t* xq, uint32_t xq_stride, float* ssq, uint32_t ssq_stride, hipStream_t st);
 hipError_t moe_router_launch(const float* x, const float* norm_w, float eps, const float* w, uint32_t hidden,
                              uint32_t n_experts, uint32_t top_k, int* sel, float* sel_w, hipStream_t st, uint32_t n_tokens = 1);
 

@@ -69,6 +69,10 @@ struct BatchScratch {
   std::vector<uint32_t*> kx;
   float* kv_tmp = nullptr;
   uint64_t code_stride = 0, x_stride = 0;             // bytes / words between two slots
+  // MoE layers, experts read once per step (top-k <= 2): the (sequence, slot) pairs' activations [pair][ffn] (+ XQ views) and expert
+  // outputs [pair][hidden]; per expert the number of pairs that chose it and their list
+  float *moe_act = nullptr, *moe_tmp = nullptr;
+  int *moe_cnt = nullptr, *moe_idx = nullptr;
   std::vector<size_t> pos;                            // per slot: tokens in its cache
   hipGraphExec_t graph[kMaxBatch + 1][2] = {};        // [n_seq][0 logits only, 1 + arg-max fed back]
 };

@@ -38,7 +38,7 @@ __device__ __forceinline__ void mvqb_tail(const MvLaunch& L, const MvSeg& S, con
   if (nrm) {   // wave w: sequences w, w + waves, ... — per sequence what wave 0 of the single-sequence kernel does; slots 1..7 stay zero
     const uint32_t L_n_ssq = L.n_ssq_part, nw = blockDim.x >> 6;
     for (uint32_t s = wave; s < n_seq; s += nw) {
-      const float* part = L.ssq_part + (size_t)s * B.ssq_stride;
+      const float* part = L.ssq_part + (size_t)(B.ind_cnt ? (uint32_t)B.ind_idx[s] / B.ind_div : s) * B.ssq_stride;
       float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -59,11 +59,12 @@ __device__ __forceinline__ void mvqb_tail(const MvLaunch& L, const MvSeg& S, con
   if (grp >= n_par) return;
   for (uint32_t s = grp; s < n_seq; s += n_par) {
     const bool cache = S.epi == EPI_ROPE_K || S.epi == EPI_V_CACHE;
+    const uint32_t so = B.ind_cnt ? (uint32_t)B.ind_idx[s] : s;   // whose output vectors (an indirect entry's (sequence, slot) pair)
     MvEpiView V;
-    V.out = cache ? S.out + (size_t)B.slot[s] * B.cache_stride : S.out + (size_t)s * B.out_stride[sg];
-    V.resid = S.resid ? S.resid + (size_t)s * B.resid_stride[sg] : nullptr;
-    V.xq_out = S.xq_out ? S.xq_out + (size_t)s * B.xq_out_stride[sg] : nullptr;
-    V.xq_ssq = S.xq_ssq ? S.xq_ssq + (size_t)s * B.ssq_out_stride[sg] : nullptr;
+    V.out = cache ? S.out + (size_t)B.slot[s] * B.cache_stride : S.out + (size_t)so * B.out_stride[sg];
+    V.resid = S.resid ? S.resid + (size_t)so * B.resid_stride[sg] : nullptr;
+    V.xq_out = S.xq_out ? S.xq_out + (size_t)so * B.xq_out_stride[sg] : nullptr;
+    V.xq_ssq = S.xq_ssq ? S.xq_ssq + (size_t)so * B.ssq_out_stride[sg] : nullptr;
     V.pos = B.pos + s;
     mv_epilogue_view(L, S, V, wg, red + (size_t)s * red_floats, ssq + s * 8, nslots, MvEpiPre{0.0f, 0.0f, false}, tl);
   }
@@ -243,7 +244,13 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
   extern __shared__ __attribute__((aligned(16))) uint8_t smem8[];
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const uint32_t n_seq = B.n_seq;
+  uint32_t n_seq = B.n_seq;
+  if (B.ind_cnt) {   // indirect entries (MoE expert launch): how many (sequence, slot) pairs chose this expert — possibly none
+    uint32_t cw;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt) : "memory");
+    n_seq = min(cw, n_seq);
+    if (n_seq == 0) return;
+  }
   const uint32_t u = blockIdx.x * kBWaves + wave;                 // this wave's unit
   const bool active = u < Gm.n_units;
   const int sg = (int)(u >= Gm.ub1) + (int)(u >= Gm.ub2);
@@ -303,7 +310,8 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
       if (i < pieces) {
         const uint32_t rec = i / (kXqRecord / 16), off = i - rec * (kXqRecord / 16);
         const uint32_t bi = rec / n_seq, s = rec - bi * n_seq;
-        stg[j] = *reinterpret_cast<const u32x4*>(xg + (size_t)s * B.xq_stride + (size_t)(b0 + bi) * kXqRecord + off * 16);
+        const uint32_t sx = B.ind_cnt ? (uint32_t)B.ind_idx[s] / B.ind_div : s;   // whose input vector
+        stg[j] = *reinterpret_cast<const u32x4*>(xg + (size_t)sx * B.xq_stride + (size_t)(b0 + bi) * kXqRecord + off * 16);
       }
     }
   };
@@ -393,7 +401,7 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
     const size_t rows16 = (size_t)Gm.n_units * 16;
 #pragma unroll
     for (int s = 0; s < NB; s++)
-      if ((uint32_t)s < n_seq) part[((size_t)slot * n_seq + s) * rows16 + (size_t)u * 16 + n] = tot[s];
+      if ((uint32_t)s < n_seq) part[((size_t)slot * B.n_seq + s) * rows16 + (size_t)u * 16 + n] = tot[s];
   }
 }
 
@@ -410,7 +418,14 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_epilogue_kernel(uint32_t w
   const uint32_t Rg = L.nseg > 1 ? S.rows_per_wg >> (4 + __builtin_ctz(S_G)) : geom2 >> 16;
   const uint32_t S_rpw = 16u * Rg * S_G;
   const uint32_t wg = bid - S.wg_begin;
-  const uint32_t n_seq = B.n_seq, nslots = Gm.nslots;
+  uint32_t n_seq = B.n_seq;
+  if (B.ind_cnt) {
+    uint32_t cw;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt) : "memory");
+    n_seq = min(cw, n_seq);
+    if (n_seq == 0) return;
+  }
+  const uint32_t nslots = Gm.nslots;
   const uint32_t npass = (uint32_t)S.npass;
   float* red = reinterpret_cast<float*>(smem8);           // [n_seq][red_floats]: red[(p * nslots + slot) * S_rpw + rl]
   float* ssq = red + (size_t)n_seq * red_floats;          // [n_seq][8]
@@ -424,7 +439,7 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_epilogue_kernel(uint32_t w
     const uint32_t p = ps / nslots, slot = ps - p * nslots;
     const uint32_t row = wg * S_rpw + rl;
     float v = 0.0f;
-    if (row < ntiles * 16) v = part[((size_t)slot * n_seq + s) * rows16 + (size_t)(ub + p * ntiles) * 16 + row];
+    if (row < ntiles * 16) v = part[((size_t)slot * B.n_seq + s) * rows16 + (size_t)(ub + p * ntiles) * 16 + row];
     red[(size_t)s * red_floats + j] = v;
   }
   mvqb_tail(L, S, B, sg, wg, nrm, n_seq, red_floats, red, ssq, nslots);
@@ -482,6 +497,7 @@ hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint3
     if (L.seg[i].npass > 2 || L.seg[i].pass[0].sel || (L.seg[i].npass == 2 && L.seg[i].pass[1].xq != L.seg[i].pass[0].xq)) return hipErrorInvalidValue;
   const size_t lds = mvqb_lds_bytes(B.n_seq, L.red_floats);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (B.ind_cnt && (B.part == nullptr || B.n_seq < mvqb2_min_seq() || !B.ind_idx || B.ind_div == 0)) return hipErrorInvalidValue;   // indirect entries: mvqb2 only
   bool shared_x = B.part != nullptr;
   for (int i = 0; i < L.nseg; i++) shared_x = shared_x && L.seg[i].pass[0].xq == L.seg[0].pass[0].xq;
   if (shared_x && B.n_seq >= mvqb2_min_seq()) {
@@ -514,6 +530,7 @@ hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint3
 #undef LGH_MVQB2_CASE
     }
   }
+  if (B.ind_cnt) return hipErrorInvalidValue;   // (indirect entries exist in the mvqb2 structure only)
 #define LGH_MVQB_NB(M, NBV) return mvqb_go<M, NBV>(L, B, g, threads, lds, st)
 #define LGH_MVQB_CASE(M)                                         \
   case M:                                                        \

@@ -1,6 +1,7 @@
 // misc.hip — small decode-path kernels: standalone RMSNorm / RoPE / SiLU*mul (per-op surface and
 // fallbacks for shapes the fused epilogues do not cover), device arg-max, MoE router.
 #include "device_utils.h"
+#include "xq.h"
 #include "timeline.h"
 
 LGH_TL_DEFINE(misc)
@@ -292,6 +293,49 @@ __global__ void advance_kernel(int* state) {
 
 hipError_t advance_launch(int* state, hipStream_t st) {
   hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, state);
+  return hipGetLastError();
+}
+
+// ---- MoE layers of a multi-sequence step (engine_batch.hip): the step's (sequence, top-k slot) pairs grouped by expert, so that an
+// expert's matrices are read ONCE for all sequences that selected it (the reference's BatchedEngine runs MoeLayer::forward,
+// moe.rs:321-413, per sequence).  sel: [n_seq][8] expert ids (the router's output, selection order); idx[e][j] = the j-th pair
+// v = sequence * top_k + slot that chose expert e, sequences ascending; cnt[e] = how many.
+__global__ void moe_group_kernel(const int* __restrict__ sel, uint32_t n_seq, uint32_t top_k, uint32_t n_experts, int* __restrict__ cnt,
+                                 int* __restrict__ idx, uint32_t idx_stride) {
+  const uint32_t e = threadIdx.x;
+  if (e >= n_experts) return;
+  int c = 0;
+  for (uint32_t s = 0; s < n_seq; s++)
+    for (uint32_t p = 0; p < top_k; p++)
+      if ((uint32_t)sel[s * 8 + p] == e) idx[e * idx_stride + c++] = (int)(s * top_k + p);
+  cnt[e] = c;
+}
+
+hipError_t moe_group_launch(const int* sel, uint32_t n_seq, uint32_t top_k, uint32_t n_experts, int* cnt, int* idx, uint32_t idx_stride, hipStream_t st) {
+  if (n_experts > 64 || top_k == 0 || top_k > 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moe_group_kernel, dim3(1), dim3(64), 0, st, sel, n_seq, top_k, n_experts, cnt, idx, idx_stride);
+  return hipGetLastError();
+}
+
+// h[s] = (sum_p w[s][p] * down_p) + h[s], the experts in selection order from a zero-initialised sum (moe.rs:363-368; the
+// single-sequence EPI_MOE_DOWN epilogue, mv_epilogue.h, operation for operation), + the XQ image of the new h times the next
+// consumer's norm weights and the per-chunk sums of squares.  tmp: [n_seq * top_k][H] expert outputs; grid (H / 256, n_seq).
+__global__ void __launch_bounds__(256) moe_combine_kernel(const float* __restrict__ tmp, const float* __restrict__ moe_w, uint32_t top_k, float* __restrict__ hidden,
+                                                          uint32_t H, const float* __restrict__ nw, uint8_t* __restrict__ xq, uint32_t xq_stride,
+                                                          float* __restrict__ ssq, uint32_t ssq_stride) {
+  const uint32_t s = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= H) return;
+  float acc = 0.0f;
+  for (uint32_t p = 0; p < top_k; p++) acc += moe_w[s * 8 + p] * tmp[((size_t)s * top_k + p) * H + row];
+  const float outv = acc + hidden[(size_t)s * H + row];
+  hidden[(size_t)s * H + row] = outv;
+  if (xq) xq_store_chunk(xq + (size_t)s * xq_stride, row >> 4, outv * (nw ? nw[row] : 1.0f), ssq ? ssq + (size_t)s * ssq_stride : nullptr, outv);
+}
+
+hipError_t moe_combine_launch(const float* tmp, const float* moe_w, uint32_t top_k, float* hidden, uint32_t H, uint32_t n_seq, const float* nw,
+                              uint8_t* xq, uint32_t xq_stride, float* ssq, uint32_t ssq_stride, hipStream_t st) {
+  if (H % 256 || n_seq == 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(moe_combine_kernel, dim3(H / 256, n_seq), dim3(256), 0, st, tmp, moe_w, top_k, hidden, H, nw, xq, xq_stride, ssq, ssq_stride);
   return hipGetLastError();
 }
 

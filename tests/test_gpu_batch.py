@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _engines(pkg, name, mix, max_seq=96, n_single=1, **kw):
+    if name == "test-moe-e1024":
+        # expert width 1024 (4 blocks of 256 -> 8-wave plans, like Mixtral's 14336): the step reads every selected expert ONCE for
+        # all sequences that chose it (engine_batch.hip); "test-moe" (768: 3 blocks) stays on the sequence-by-sequence MoE path
+        name, kw = "test-moe", dict(kw, expert_intermediate_size=1024)
     cfg = pkg.make_config(name, max_seq_len=max_seq, **kw)
     model = pkg.SynthModel(cfg, mix=mix)
     multi = pkg.HipGpuInference.from_model(model, max_seq)
@@ -33,7 +37,8 @@ def _history(cfg, seq, n):
                                         ("test-dense-d128", "Q4_K_M", 4), ("test-dense-d128", "Q4_K_M", 8), ("test-dense-d128", "Q4_K_M", 16),
                                         ("test-dense", "Q8_0", 3), ("test-dense", "Q5_K_M", 4), ("test-dense", "Q6_K", 7), ("test-dense", "Q4_0", 2),
                                         ("test-dense", "Q5_K_M", 12), ("test-dense", "Q8_0", 9), ("test-dense-d128", "Q6_K", 16),
-                                        ("test-moe", "Q5_K_M", 3), ("test-moe", "Q4_K_M", 16)])
+                                        ("test-moe", "Q5_K_M", 3), ("test-moe", "Q4_K_M", 16),
+                                        ("test-moe-e1024", "Q5_K_M", 3), ("test-moe-e1024", "Q4_K_M", 16), ("test-moe-e1024", "Q8_0", 7)])
 def test_every_sequence_gets_the_single_sequence_logits_bitwise(pkg, name, mix, B):
     """B sequences with different histories and RAGGED lengths, token by token through lgh_forward_multi; each sequence's logits
     at every step equal, bit for bit, those of a single-sequence engine fed the same history."""
