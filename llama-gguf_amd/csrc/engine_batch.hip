@@ -5,8 +5,9 @@
 // `model.forward` for each active sequence in turn: B sequences read the weights B times.  Here a context owns `max_batch`
 // SLOTS — a slot = one sequence's KV caches + position — and lgh_forward_multi feeds one token to each listed slot in ONE pass
 // over the weights: every quantized mat-vec launch reads its tiles once and multiplies them with all n_seq input vectors
-// (matvec_batch.hip), attention / its merge / embedding / arg-max run with the sequence as the grid's second dimension, MoE
-// layers' expert FFN sequence by sequence (each sequence routes to its own experts).  Every sequence's logits are
+// (matvec_batch.hip), attention / its merge / embedding / arg-max run with the sequence as the grid's second dimension (over f32 or
+// TurboQuant slots); MoE layers route every sequence to its own experts: from 7 sequences on the step's (sequence, slot) pairs are
+// grouped by expert and each selected expert is read once, below that the FFN runs sequence by sequence.  Every sequence's logits are
 // bit-identical to what the single-sequence engine computes for the same tokens (tests/test_gpu_batch.py): same kernels'
 // arithmetic, same summation orders.
 //

@@ -15,8 +15,9 @@
 // workgroup = the 8 k-slices of a few row tiles) with a loop over the sequences inside it and their records from L2 into a
 // register ring; kept for one sequence and for launches whose segments do not share their input vector.
 // Epilogues: store, +residual, SwiGLU pair, RoPE (every sequence at its own position) and the K / V rows into the sequence's
-// own cache slot; optional XQ image of the output for the next launch.  MoE experts are not batched (every sequence selects
-// its own experts): engine_batch.hip runs those layers' FFN sequence by sequence through the single-sequence kernel.
+// own cache slot; optional XQ image of the output for the next launch.  MoE layers: an expert launch works on an INDIRECT
+// entry list (MvBatch::ind_*: the (sequence, top-k slot) pairs that chose the expert, their number read from device memory), so
+// that an expert's matrices are read once per step; below 7 sequences engine_batch.hip runs the FFN sequence by sequence instead.
 #include <algorithm>
 #include <cstdlib>
 
