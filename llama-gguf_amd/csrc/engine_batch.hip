@@ -73,11 +73,12 @@ void spread_state(lgh_ctx* c, const float* f32, uint32_t k, uint32_t n) {
 // one batched quantized mat-vec launch: `specs` name sequence 0's vectors
 struct MvIndirect { const int* cnt = nullptr; const int* idx = nullptr; uint32_t div = 0; };
 
-// MoE layers: from how many sequences on a step reads every selected expert ONCE (34 launches per layer whatever the step's size)
-// instead of running the FFN sequence by sequence (3 launches per sequence).  Measured on Mixtral-8x7B Q5_K_M, tokens/s grouped vs
-// sequence by sequence: 4 sequences 365 vs 442, 6: 440 vs 456, 8: 510 vs 468, 16: 688 vs 480 (profiles/r03e_batched_decode.md).
+// MoE layers: from how many sequences on a step reads every selected expert ONCE (one router launch, a grouping launch, 4 launches
+// per expert, one combine: 35 per layer whatever the step's size) instead of running the FFN sequence by sequence (3 launches per
+// sequence).  Measured on Mixtral-8x7B Q5_K_M, tokens/s grouped vs sequence by sequence: 3 sequences 332 vs 419, 4: 394 vs 438,
+// 6: 484 vs 455, 8: 570 vs 468, 16: 818 vs 480 (profiles/r03e_batched_decode.md).
 uint32_t moe_group_min() {
-  static const uint32_t v = [] { const char* e = std::getenv("LGH_MOE_GROUP_MIN"); return e ? (uint32_t)std::max(2, std::atoi(e)) : 7u; }();
+  static const uint32_t v = [] { const char* e = std::getenv("LGH_MOE_GROUP_MIN"); return e ? (uint32_t)std::max(2, std::atoi(e)) : 6u; }();
   return v;
 }
 
@@ -270,11 +271,11 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
       // router per sequence -> the (sequence, slot) pairs grouped by expert -> per expert a gate|up launch over its pairs
       // (SwiGLU, activation + XQ image per pair) and a down launch (output per pair) -> h += sum_p w_p * down_p in selection order
       const uint32_t topk = d.num_experts_per_token, ne = d.num_experts, EF = Lw.gate_exps.n;
-      for (uint32_t s = 0; s < n_seq; s++)
-        if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)ne * H * 4, [&] {
-               return moe_router_launch(Bs.hidden + (size_t)s * H, Lw.ffn_norm, d.norm_eps, Lw.router, H, ne, topk, Bs.moe_sel + s * 8, Bs.moe_w + s * 8, c->stream);
-             })))
-          return rc;
+      // (the router for all sequences in one launch: selections and weights packed [sequence][top_k])
+      if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)ne * H * 4, [&] {
+             return moe_router_launch(Bs.hidden, Lw.ffn_norm, d.norm_eps, Lw.router, H, ne, topk, Bs.moe_sel, Bs.moe_w, c->stream, n_seq);
+           })))
+        return rc;
       if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return moe_group_launch(Bs.moe_sel, n_seq, topk, ne, Bs.moe_cnt, Bs.moe_idx, kMaxBatch, c->stream); })))
         return rc;
       auto expert = [&](const DevWeight& W, uint32_t e) {

@@ -298,16 +298,15 @@ hipError_t advance_launch(int* state, hipStream_t st) {
 
 // ---- MoE layers of a multi-sequence step (engine_batch.hip): the step's (sequence, top-k slot) pairs grouped by expert, so that an
 // expert's matrices are read ONCE for all sequences that selected it (the reference's BatchedEngine runs MoeLayer::forward,
-// moe.rs:321-413, per sequence).  sel: [n_seq][8] expert ids (the router's output, selection order); idx[e][j] = the j-th pair
+// moe.rs:321-413, per sequence).  sel: [n_seq][top_k] expert ids (the router's output, selection order); idx[e][j] = the j-th pair
 // v = sequence * top_k + slot that chose expert e, sequences ascending; cnt[e] = how many.
 __global__ void moe_group_kernel(const int* __restrict__ sel, uint32_t n_seq, uint32_t top_k, uint32_t n_experts, int* __restrict__ cnt,
                                  int* __restrict__ idx, uint32_t idx_stride) {
   const uint32_t e = threadIdx.x;
   if (e >= n_experts) return;
   int c = 0;
-  for (uint32_t s = 0; s < n_seq; s++)
-    for (uint32_t p = 0; p < top_k; p++)
-      if ((uint32_t)sel[s * 8 + p] == e) idx[e * idx_stride + c++] = (int)(s * top_k + p);
+  for (uint32_t v = 0; v < n_seq * top_k; v++)   // sel: [n_seq][top_k], the router's multi-token layout
+    if ((uint32_t)sel[v] == e) idx[e * idx_stride + c++] = (int)v;
   cnt[e] = c;
 }
 
@@ -326,7 +325,7 @@ __global__ void __launch_bounds__(256) moe_combine_kernel(const float* __restric
   const uint32_t s = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
   if (row >= H) return;
   float acc = 0.0f;
-  for (uint32_t p = 0; p < top_k; p++) acc += moe_w[s * 8 + p] * tmp[((size_t)s * top_k + p) * H + row];
+  for (uint32_t p = 0; p < top_k; p++) acc += moe_w[s * top_k + p] * tmp[((size_t)s * top_k + p) * H + row];
   const float outv = acc + hidden[(size_t)s * H + row];
   hidden[(size_t)s * H + row] = outv;
   if (xq) xq_store_chunk(xq + (size_t)s * xq_stride, row >> 4, outv * (nw ? nw[row] : 1.0f), ssq ? ssq + (size_t)s * ssq_stride : nullptr, outv);
