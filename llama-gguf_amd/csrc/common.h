@@ -167,6 +167,11 @@ struct MvBatch {
   const int* ind_cnt;
   const int* ind_idx;
   uint32_t ind_div;
+  // ... and all experts of a layer in ONE launch: blockIdx.z = the expert — its count is ind_cnt[z], its entry list ind_idx + z *
+  // ind_stride, its matrices the launch's planes + z * (the stack stride in MvPass::sel_stride), its partial sums a region of their own
+  uint32_t ind_stride;
+  uint32_t ind_nz;            // experts in the launch (grid z); 0 / 1: a single entry list
+  uint64_t part_z_floats;     // (set by the launcher)
 };
 
 // launch-uniform geometry of one int8-MFMA launch as the kernel takes it (mvq_pack)

@@ -71,14 +71,15 @@ void spread_state(lgh_ctx* c, const float* f32, uint32_t k, uint32_t n) {
 }
 
 // one batched quantized mat-vec launch: `specs` name sequence 0's vectors
-struct MvIndirect { const int* cnt = nullptr; const int* idx = nullptr; uint32_t div = 0; };
+struct MvIndirect { const int* cnt = nullptr; const int* idx = nullptr; uint32_t div = 0, nz = 0, stride = 0; };
 
-// MoE layers: from how many sequences on a step reads every selected expert ONCE (one router launch, a grouping launch, 4 launches
-// per expert, one combine: 35 per layer whatever the step's size) instead of running the FFN sequence by sequence (3 launches per
-// sequence).  Measured on Mixtral-8x7B Q5_K_M, tokens/s grouped vs sequence by sequence: 3 sequences 332 vs 419, 4: 394 vs 438,
-// 6: 484 vs 455, 8: 570 vs 468, 16: 818 vs 480 (profiles/r03e_batched_decode.md).
+// MoE layers: from how many sequences on a step reads every selected expert ONCE (one router launch, a grouping launch, gate | up
+// and down over all experts with the expert as the grid's third dimension + their epilogue launches, one combine: 7 per layer
+// whatever the step's size) instead of running the FFN sequence by sequence (3 launches per sequence).  Measured on Mixtral-8x7B
+// Q5_K_M, tokens/s grouped vs sequence by sequence: 2 sequences 363 vs 392, 3: 447 vs 421, 4: 520 vs 436, 8: 764 vs 468,
+// 16: 1 030 vs 480 (profiles/r03e_batched_decode.md).
 uint32_t moe_group_min() {
-  static const uint32_t v = [] { const char* e = std::getenv("LGH_MOE_GROUP_MIN"); return e ? (uint32_t)std::max(2, std::atoi(e)) : 6u; }();
+  static const uint32_t v = [] { const char* e = std::getenv("LGH_MOE_GROUP_MIN"); return e ? (uint32_t)std::max(2, std::atoi(e)) : 3u; }();
   return v;
 }
 
@@ -109,6 +110,8 @@ int launch_mvb(lgh_ctx* c, int cls, const SegSpec* specs, int nseg, const float*
   B.ind_cnt = ind.cnt;
   B.ind_idx = ind.idx;
   B.ind_div = ind.div;
+  B.ind_nz = ind.nz;
+  B.ind_stride = ind.stride;
   {   // the input vector's images lie at the strides its views were registered with
     const XqBuf* q0 = view_of(c, specs[0].x[0]);
     const uint32_t kreg = q0 ? q0->k : k;
@@ -278,32 +281,26 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
         return rc;
       if ((rc = run_k(c, LGH_K_MISC, LGH_SYM_OTHER, 0, [&] { return moe_group_launch(Bs.moe_sel, n_seq, topk, ne, Bs.moe_cnt, Bs.moe_idx, kMaxBatch, c->stream); })))
         return rc;
-      auto expert = [&](const DevWeight& W, uint32_t e) {
-        DevWeight We = W;
-        for (int i = 0; i < 4; i++) if (We.plane[i]) We.plane[i] += (uint64_t)e * We.stack_stride[i];
-        We.n_stack = 1;
-        return We;
-      };
-      for (uint32_t e = 0; e < ne; e++) {
-        const DevWeight g = expert(Lw.gate_exps, e), u = expert(Lw.up_exps, e);
+      // all experts of the layer in one launch each (grid z = expert: its count, its entry list, its slice of the stacked matrices)
+      const MvIndirect ind_gu{Bs.moe_cnt, Bs.moe_idx, topk, ne, (uint32_t)kMaxBatch}, ind_dn{Bs.moe_cnt, Bs.moe_idx, 1, ne, (uint32_t)kMaxBatch};
+      {
         SegSpec sp;
         sp.npass = 2;
-        sp.W[0] = &g; sp.W[1] = &u;
+        sp.W[0] = &Lw.gate_exps; sp.W[1] = &Lw.up_exps;
         sp.x[0] = sp.x[1] = Bs.hidden;
         sp.epi = EPI_SWIGLU;
         sp.out = Bs.moe_act;
         sp.xq_next = 1;
         const uint32_t os[1] = {EF}, rs[1] = {0}, xk[1] = {EF};
-        if ((rc = launch_mvb(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H, n_seq, os, rs, xk, MvIndirect{Bs.moe_cnt + e, Bs.moe_idx + e * kMaxBatch, topk}))) return rc;
+        if ((rc = launch_mvb(c, LGH_K_GATEUP, &sp, 1, Lw.ffn_norm, H, n_seq, os, rs, xk, ind_gu))) return rc;
       }
       for (uint32_t v = 0; v < n_seq * topk; v++)
         if (XqBuf* q = view_of(c, Bs.moe_act + (size_t)v * EF)) { q->fresh = true; q->tag = nullptr; }
-      for (uint32_t e = 0; e < ne; e++) {
-        const DevWeight dn = expert(Lw.down_exps, e);
+      {
         SegSpec sp;
-        sp.W[0] = &dn; sp.x[0] = Bs.moe_act; sp.epi = EPI_STORE; sp.out = Bs.moe_tmp;
+        sp.W[0] = &Lw.down_exps; sp.x[0] = Bs.moe_act; sp.epi = EPI_STORE; sp.out = Bs.moe_tmp;
         const uint32_t os[1] = {H}, rs[1] = {0}, xk[1] = {0};
-        if ((rc = launch_mvb(c, LGH_K_DOWN, &sp, 1, nullptr, dn.k, n_seq, os, rs, xk, MvIndirect{Bs.moe_cnt + e, Bs.moe_idx + e * kMaxBatch, 1}))) return rc;
+        if ((rc = launch_mvb(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k, n_seq, os, rs, xk, ind_dn))) return rc;
       }
       {
         XqBuf* qh = view_of(c, Bs.hidden);
@@ -422,7 +419,8 @@ int lgh_batch_create(lgh_ctx* c, uint32_t max_batch) {
   const size_t B = max_batch;
   // partial sums between the two launches of a multi-sequence mat-vec (matvec_batch.hip, mvqb2): per sequence either one value per
   // launch row (any matrix) or 8 slices x the rows of a matrix with fewer than 1600 row tiles
-  Bs.mv_part_floats = B * std::max<uint64_t>({(uint64_t)8 * 1600 * 16, (uint64_t)d.vocab_size + 16, (uint64_t)2 * ffn, (uint64_t)QD + 2 * d.num_kv_heads * d.head_dim, (uint64_t)H});
+  const uint64_t moe_part = d.num_experts ? (uint64_t)d.num_experts * std::max<uint64_t>((uint64_t)2 * EI, (uint64_t)8 * H) : 0;   // every expert's region
+  Bs.mv_part_floats = B * std::max<uint64_t>({moe_part, (uint64_t)8 * 1600 * 16, (uint64_t)d.vocab_size + 16, (uint64_t)2 * ffn, (uint64_t)QD + 2 * d.num_kv_heads * d.head_dim, (uint64_t)H});
   uint8_t *xq_h = nullptr, *xq_a = nullptr, *xq_f = nullptr, *xq_f2 = nullptr;
   float *ssq_h = nullptr, *ssq_a = nullptr, *ssq_f = nullptr, *ssq_f2 = nullptr;
   struct { void** p; size_t n; } bufs[] = {

@@ -33,13 +33,13 @@ constexpr int kBWaves = 8;
 // ---- the tail of a multi-sequence launch: per sequence the RMSNorm's sum of squares (exactly the single-sequence kernel's
 // order), then the single-sequence epilogue on that sequence's vectors.  red: [n_seq][red_floats], ssq: [n_seq][8] (LDS)
 __device__ __forceinline__ void mvqb_tail(const MvLaunch& L, const MvSeg& S, const MvBatch& B, int sg, uint32_t wg, bool nrm, uint32_t n_seq,
-                                          uint32_t red_floats, float* red, float* ssq, uint32_t nslots) {
+                                          uint32_t red_floats, float* red, float* ssq, uint32_t nslots, const int* ind_idx = nullptr) {
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if (nrm) {   // wave w: sequences w, w + waves, ... — per sequence what wave 0 of the single-sequence kernel does; slots 1..7 stay zero
     const uint32_t L_n_ssq = L.n_ssq_part, nw = blockDim.x >> 6;
     for (uint32_t s = wave; s < n_seq; s += nw) {
-      const float* part = L.ssq_part + (size_t)(B.ind_cnt ? (uint32_t)B.ind_idx[s] / B.ind_div : s) * B.ssq_stride;
+      const float* part = L.ssq_part + (size_t)(ind_idx ? (uint32_t)ind_idx[s] / B.ind_div : s) * B.ssq_stride;
       float ssp[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -60,7 +60,7 @@ __device__ __forceinline__ void mvqb_tail(const MvLaunch& L, const MvSeg& S, con
   if (grp >= n_par) return;
   for (uint32_t s = grp; s < n_seq; s += n_par) {
     const bool cache = S.epi == EPI_ROPE_K || S.epi == EPI_V_CACHE;
-    const uint32_t so = B.ind_cnt ? (uint32_t)B.ind_idx[s] : s;   // whose output vectors (an indirect entry's (sequence, slot) pair)
+    const uint32_t so = ind_idx ? (uint32_t)ind_idx[s] : s;   // whose output vectors (an indirect entry's (sequence, slot) pair)
     MvEpiView V;
     V.out = cache ? S.out + (size_t)B.slot[s] * B.cache_stride : S.out + (size_t)so * B.out_stride[sg];
     V.resid = S.resid ? S.resid + (size_t)so * B.resid_stride[sg] : nullptr;
@@ -246,11 +246,15 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
   const uint32_t tid = threadIdx.x, lane = tid & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t n_seq = B.n_seq;
+  const uint32_t ez = blockIdx.z;                                 // expert (indirect launches over a layer's experts; else 0)
+  const int* ind_idx = nullptr;
   if (B.ind_cnt) {   // indirect entries (MoE expert launch): how many (sequence, slot) pairs chose this expert — possibly none
     uint32_t cw;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt + ez) : "memory");
     n_seq = min(cw, n_seq);
     if (n_seq == 0) return;
+    ind_idx = B.ind_idx + (size_t)ez * B.ind_stride;
+    part += (size_t)ez * B.part_z_floats;
   }
   const uint32_t u = blockIdx.x * kBWaves + wave;                 // this wave's unit
   const bool active = u < Gm.n_units;
@@ -264,7 +268,8 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
   const uint32_t ntiles = (S.n_rows + 15) >> 4;
   const uint32_t ul = u - (sg == 0 ? 0u : sg == 1 ? Gm.ub1 : Gm.ub2);
   const uint32_t pass = active ? ul / ntiles : 0, tl = active ? ul - pass * ntiles : 0;
-  const uint8_t* wbase = (pass == 0 ? S.pass[0].plane[0] : S.pass[1].plane[0]) + (size_t)tl * Gm.nblk * tb;
+  const uint8_t* wbase = (pass == 0 ? S.pass[0].plane[0] + (uint64_t)ez * S.pass[0].sel_stride[0] : S.pass[1].plane[0] + (uint64_t)ez * S.pass[1].sel_stride[0]) +
+                         (size_t)tl * Gm.nblk * tb;
   const uint8_t* xg = L.seg[0].pass[0].xq;                        // sequence 0's records (all segments and passes share the input)
   const uint32_t n = lane & 15, mq = lane >> 4;
 
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
       if (i < pieces) {
         const uint32_t rec = i / (kXqRecord / 16), off = i - rec * (kXqRecord / 16);
         const uint32_t bi = rec / n_seq, s = rec - bi * n_seq;
-        const uint32_t sx = B.ind_cnt ? (uint32_t)B.ind_idx[s] / B.ind_div : s;   // whose input vector
+        const uint32_t sx = ind_idx ? (uint32_t)ind_idx[s] / B.ind_div : s;   // whose input vector
         stg[j] = *reinterpret_cast<const u32x4*>(xg + (size_t)sx * B.xq_stride + (size_t)(b0 + bi) * kXqRecord + off * 16);
       }
     }
@@ -420,11 +425,14 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_epilogue_kernel(uint32_t w
   const uint32_t S_rpw = 16u * Rg * S_G;
   const uint32_t wg = bid - S.wg_begin;
   uint32_t n_seq = B.n_seq;
+  const int* ind_idx = nullptr;
   if (B.ind_cnt) {
     uint32_t cw;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"(B.ind_cnt + blockIdx.z) : "memory");
     n_seq = min(cw, n_seq);
     if (n_seq == 0) return;
+    ind_idx = B.ind_idx + (size_t)blockIdx.z * B.ind_stride;
+    part += (size_t)blockIdx.z * B.part_z_floats;
   }
   const uint32_t nslots = Gm.nslots;
   const uint32_t npass = (uint32_t)S.npass;
@@ -443,7 +451,7 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_epilogue_kernel(uint32_t w
     if (row < ntiles * 16) v = part[((size_t)slot * B.n_seq + s) * rows16 + (size_t)(ub + p * ntiles) * 16 + row];
     red[(size_t)s * red_floats + j] = v;
   }
-  mvqb_tail(L, S, B, sg, wg, nrm, n_seq, red_floats, red, ssq, nslots);
+  mvqb_tail(L, S, B, sg, wg, nrm, n_seq, red_floats, red, ssq, nslots, ind_idx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,16 +471,17 @@ template <uint32_t MASK, int NB>
 static hipError_t mvqb2_go(const MvLaunch& L, const MvBatch& B, const MvGeom& g, const Mvqb2Geom& Gm, bool seq, uint32_t groups, size_t lds_x,
                            size_t lds_e, uint32_t threads, hipStream_t st) {
   static bool attr_set[3][64] = {};
+  const uint32_t nz = B.ind_cnt && B.ind_nz > 1 ? B.ind_nz : 1;   // a layer's experts as the grid's third dimension
   if (seq) {
     if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvqb2_kernel<MASK, NB, true>), 160 * 1024, attr_set[0]); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mvqb2_kernel<MASK, NB, true>), dim3(groups), dim3(kBWaves * 64), lds_x, st, Gm, L, B, B.part);
+    hipLaunchKernelGGL((mvqb2_kernel<MASK, NB, true>), dim3(groups, 1, nz), dim3(kBWaves * 64), lds_x, st, Gm, L, B, B.part);
   } else {
     if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvqb2_kernel<MASK, NB, false>), 160 * 1024, attr_set[1]); e != hipSuccess) return e;
-    hipLaunchKernelGGL((mvqb2_kernel<MASK, NB, false>), dim3(groups, Gm.T), dim3(kBWaves * 64), lds_x, st, Gm, L, B, B.part);
+    hipLaunchKernelGGL((mvqb2_kernel<MASK, NB, false>), dim3(groups, Gm.T, nz), dim3(kBWaves * 64), lds_x, st, Gm, L, B, B.part);
   }
   if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&mvqb2_epilogue_kernel), 160 * 1024, attr_set[2]); e != hipSuccess) return e;
-  hipLaunchKernelGGL(mvqb2_epilogue_kernel, dim3(g.n_wg), dim3(threads), lds_e, st, g.wbpack, g.geom, g.geom2, L.red_floats, Gm, L, B,
+  hipLaunchKernelGGL(mvqb2_epilogue_kernel, dim3(g.n_wg, 1, nz), dim3(threads), lds_e, st, g.wbpack, g.geom, g.geom2, L.red_floats, Gm, L, B,
                      (const float*)B.part);
   return hipGetLastError();
 }
@@ -488,7 +497,8 @@ static uint32_t mvqb2_min_seq() {
 
 // `L` built like a single-sequence launch (engine.hip: build_mv_group, with the batch cap on tiles per workgroup); sequences'
 // vectors at the strides in `B`
-hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& Bin, uint32_t n_wg, uint32_t threads, hipStream_t st) {
+  MvBatch B = Bin;
   if (B.n_seq == 0 || B.n_seq > (uint32_t)kMaxBatch || threads != kBWaves * 64) return hipErrorInvalidValue;
   MvGeom g;
   size_t lds1 = 0;
@@ -517,7 +527,8 @@ hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& B, uint32_t n_wg, uint3
     const int nb_inst = B.n_seq <= 4 ? 4 : B.n_seq <= 8 ? 8 : 16;
     Gm.cb = std::max(1u, std::min(Gm.nbw, mvqb2_stage_bytes((mask & (mask - 1)) == 0, nb_inst) / (B.n_seq * (uint32_t)kXqRecord)));
     const size_t lds_x = (size_t)2 * Gm.cb * B.n_seq * kXqRecord + kXZeroBytes;
-    if ((uint64_t)Gm.nslots * B.n_seq * Gm.n_units * 16 <= B.part_floats) {
+    B.part_z_floats = (uint64_t)Gm.nslots * B.n_seq * Gm.n_units * 16;
+    if (B.part_z_floats * (B.ind_cnt && B.ind_nz > 1 ? B.ind_nz : 1) <= B.part_floats) {
 #define LGH_MVQB2_CASE(M)                                                                         \
   case M:                                                                                         \
     if (B.n_seq <= 4) return mvqb2_go<M, 4>(L, B, g, Gm, seq, groups, lds_x, lds, threads, st);  \
