@@ -256,12 +256,16 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     PfRaw w[kPfRT];
 #pragma unroll
     for (int r = 0; r < kPfRT; r++) w[r] = nxt[r];
+#if PF_EXP != 4 && PF_EXP != 6   /* experiment 4 / 6: no activation slabs after the first */
     if (b + 1 < b1) x_dma(b + 1, cur ^ 1);
+#endif
+#if PF_EXP != 5 && PF_EXP != 6   /* experiment 5 / 6: no weight loads after the first block's */
     {
       const uint32_t bn = b + 1 < b1 ? b + 1 : b;   // the last iteration re-requests its own block (unconditional loads)
 #pragma unroll
       for (int r = 0; r < kPfRT; r++) pf_load<F>(nxt[r], wt[r] + (size_t)bn * tb, lane, n);
     }
+#endif
     // The block's 32 units (MFMA step pp, half h, row tile r) as a software pipeline, one scheduling region per unit:
     // the unit's 8 MFMAs, the dequantization of the NEXT unit's A fragment, and — in the first unit of a (pp, h) phase —
     // the LDS reads of the next phase's activation fragments.  Measured on Llama-3-8B Q4_K_M (128 tokens, 4.9 ms): with
@@ -269,7 +273,8 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
     // sched_group_barrier changed nothing (4.94 vs 4.88 ms).  Phase stamps of the gate|up GEMM (tools/pf_phases.py, the PF_EXP
     // switches below; 224 workgroups, 256 MFMAs + ~720 VALU ops per wave and block): 4.3 us per block as written, 3.3 us with
     // MFMAs only (no dequantization, no LDS reads: 1.3 PFLOP/s chip-wide, what f16 MFMAs sustain here with every CU issuing
-    // them), 3.7 us with the dequantization and LDS reads only — the two overlap to within 30 %, the wait + barrier at the end
+    // them; PF_EXP 4 / 5 / 6 — no activation slabs / no weight loads / neither after the first block — 4.35 / 4.19 / 4.12 ms per pass
+    // against 4.63: the loads are not what bounds the loop), 3.7 us with the dequantization and LDS reads only — the two overlap to within 30 %, the wait + barrier at the end
     // of a block is 0.2 us.  The loop runs at 77 % of its MFMA-only rate.
     const uint8_t* xb = smem + cur * kPfSlabBytes + n * 512;
     h16x8 bf[2][MT];
