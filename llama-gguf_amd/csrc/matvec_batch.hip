@@ -239,6 +239,7 @@ constexpr uint32_t kXStageBytes = 40 * 1024;
 // (the two-format instantiations at 16 sequences have no registers to spare: smaller chunks, fewer staging registers)
 __host__ __device__ constexpr uint32_t mvqb2_stage_bytes(bool single_format, int nb) { return !single_format && nb == 16 ? 24u * 1024u : kXStageBytes; }
 constexpr uint32_t kXZeroBytes = 2 * 1280 + 256;   // the zero block; also what an odd last sequence's partner may read past the records
+constexpr uint32_t kXSelBytes = 64;                // behind it: whose input vector entry s reads (s itself, or an indirect entry's sequence)
 
 template <uint32_t MASK, int NB, bool SEQ>
 __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm, const MvLaunch L, const MvBatch B, float* __restrict__ part) {
@@ -283,6 +284,9 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
   // a masked load + a register clear per sequence, such a lane reads the zero block (one unmasked ds_read_b128 per operand).
   const uint32_t zero_off = 2 * Gm.cb * n_seq * (uint32_t)kXqRecord;   // (behind the two halves of the record buffer)
   for (uint32_t i = tid; i < kXZeroBytes / 16; i += kBWaves * 64) *reinterpret_cast<u32x4*>(smem8 + zero_off + i * 16) = u32x4{0u, 0u, 0u, 0u};
+  uint32_t* xsel = reinterpret_cast<uint32_t*>(smem8 + zero_off + kXZeroBytes);
+  if (tid < n_seq) xsel[tid] = ind_idx ? (uint32_t)ind_idx[tid] / B.ind_div : tid;
+  __syncthreads();
   const bool a_valid = (n >> 2) == mq;
   const uint32_t a_off = (mq >> 1) * 128 + (n & 3) * 32 + (mq & 1) * 16;
   const uint32_t a_step = a_valid ? (uint32_t)kXqRecord : 0u;   // per sequence
@@ -316,7 +320,7 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
       if (i < pieces) {
         const uint32_t rec = i / (kXqRecord / 16), off = i - rec * (kXqRecord / 16);
         const uint32_t bi = rec / n_seq, s = rec - bi * n_seq;
-        const uint32_t sx = ind_idx ? (uint32_t)ind_idx[s] / B.ind_div : s;   // whose input vector
+        const uint32_t sx = xsel[s];                                          // whose input vector
         stg[j] = *reinterpret_cast<const u32x4*>(xg + (size_t)sx * B.xq_stride + (size_t)(b0 + bi) * kXqRecord + off * 16);
       }
     }
@@ -526,7 +530,7 @@ hipError_t mvqb_launch(const MvLaunch& L, const MvBatch& Bin, uint32_t n_wg, uin
     Gm.nslots = seq ? 1 : Gm.T;
     const int nb_inst = B.n_seq <= 4 ? 4 : B.n_seq <= 8 ? 8 : 16;
     Gm.cb = std::max(1u, std::min(Gm.nbw, mvqb2_stage_bytes((mask & (mask - 1)) == 0, nb_inst) / (B.n_seq * (uint32_t)kXqRecord)));
-    const size_t lds_x = (size_t)2 * Gm.cb * B.n_seq * kXqRecord + kXZeroBytes;
+    const size_t lds_x = (size_t)2 * Gm.cb * B.n_seq * kXqRecord + kXZeroBytes + kXSelBytes;
     B.part_z_floats = (uint64_t)Gm.nslots * B.n_seq * Gm.n_units * 16;
     if (B.part_z_floats * (B.ind_cnt && B.ind_nz > 1 ? B.ind_nz : 1) <= B.part_floats) {
 #define LGH_MVQB2_CASE(M)                                                                         \
