@@ -60,6 +60,9 @@ static int pf_fmt_of(int dev_type) {
 #ifndef PF_WAVES
 #define PF_WAVES 4
 #endif
+#ifndef PF_SHAPE32
+#define PF_SHAPE32 0   /* experiment build (-DPF_SHAPE32=1): v_mfma_f32_32x32x16_f16 (pf_body32); product: v_mfma_f32_16x16x32_f16 (pf_body) */
+#endif
 constexpr int kPfWaves = PF_WAVES;
 constexpr int kPfRT = 16 / kPfWaves;     // row tiles per wave (a workgroup covers 256 rows)
 constexpr int kPfMT = kPfTokens / 16;    // token tiles of a full block
@@ -341,6 +344,139 @@ __device__ __forceinline__ void pf_body(const PfGemm& G, const PfSeg& sg, uint32
   LGH_PF_STAMP(14);
 }
 
+// EXPERIMENT (not in the product build; `make variant NAME=pf32 VSRC=prefill DEFS=-DPF_SHAPE32=1`), measured and not faster: Llama-3-8B
+// Q4_K_M 4.90 ms per 128-token pass against 4.82 on the same box, Mixtral 15.19 against 15.24; test_gpu_prefill.py passes on it; 290
+// registers per wave instead of 424.
+// The same GEMM on v_mfma_f32_32x32x16_f16: an MFMA holds the SIMD's vector issue port for 8 cycles whatever its shape
+// (MI355X_MICROARCH.md, cycle constants), and this loop is bound by that port — 256 MFMAs x 8 + ~700 vector instructions x 4
+// against 4096 cycles of matrix pipe per block; the 32x32x16 form does the same products with half the MFMA instructions.
+// No other layout changes: a wave's four 16-row tiles become two 32-row tiles (tile pair 2v, 2v + 1); lane l = 32g + 16sub + n
+// loads row n of tile 2v + sub and, of that row, the two 16-element chunks 2g and 2g + 1 of every 64 (the pieces lanes 16(2g + j) + n
+// of the 16-row scheme hold — the tile16 layout addresses them directly); MFMA step (pp, j, h) contracts the 16 elements
+// 64pp + 16(2g + j) + 8h .. + 7, g = 0, 1, whose activation chunks token l & 31 reads from the same XH slab.  Both chunks of a lane
+// lie in one 32-element sub-block (Q4_K / Q5_K / Q8_0 / Q4_0: one scale pair per (row tile, pp); Q6_K: one per chunk).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int F, int MT2>
+__device__ __forceinline__ void pf_body32(const PfGemm& G, const PfSeg& sg, uint32_t rg, uint32_t ks, uint32_t m_tiles, uint8_t* smem) {
+  static_assert(kPfRT % 2 == 0, "pairs of 16-row tiles");
+  constexpr int kVT = kPfRT / 2;                                       // 32-row tiles per wave
+  constexpr uint32_t kDma = (uint32_t)MT2 * 32 * 512 / kPfWaves;      // a wave's share of the MT2 * 32 rows of a slab that are copied
+  const uint32_t lane = threadIdx.x & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t n = lane & 15, sub = (lane >> 4) & 1, g = lane >> 5, tk = lane & 31;
+  constexpr uint32_t tb = pf_tile_bytes(F);
+  const uint32_t per = (G.nblk + G.S - 1) / G.S;
+  const uint32_t b0 = ks * per, b1 = b0 + per < G.nblk ? b0 + per : G.nblk;
+  const uint32_t tile0 = (rg * kPfWaves + wave) * kPfRT;
+  const uint8_t* wt[kVT];
+#pragma unroll
+  for (int v = 0; v < kVT; v++) {
+    const uint32_t tl = tile0 + 2 * v + sub < sg.ntiles ? tile0 + 2 * v + sub : sg.ntiles - 1;   // clamped: loads are unconditional
+    wt[v] = sg.w + (size_t)tl * G.nblk * tb;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+
+  f32x16 acc[kVT][MT2];
+#pragma unroll
+  for (int v = 0; v < kVT; v++)
+#pragma unroll
+    for (int t = 0; t < MT2; t++) acc[v][t] = (f32x16)(0.0f);
+
+  auto x_dma = [&](uint32_t b, uint32_t buf) {
+    const uint8_t* src = G.xh + (size_t)b * kPfSlabBytes + wave * kDma + lane * 16;
+    const uint32_t dst = lds_base + buf * kPfSlabBytes + wave * kDma;
+#pragma unroll
+    for (int i = 0; i < (int)(kDma / 1024); i++) {
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src + i * 1024), "s"(dst + i * 1024) : "memory");
+    }
+  };
+  auto w_load = [&](PfRaw (&r)[kVT][2], uint32_t b) {
+#pragma unroll
+    for (int v = 0; v < kVT; v++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) pf_load<F>(r[v][j], wt[v] + (size_t)b * tb, 16 * (2 * g + j) + n, n);
+  };
+
+  LGH_PF_STAMP(0);
+  PfRaw nxt[kVT][2];
+  if (b0 < b1) {
+    x_dma(b0, 0);
+    w_load(nxt, b0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) (the builtin: see pf_body)
+  __syncthreads();
+  LGH_PF_STAMP(1);
+  for (uint32_t b = b0; b < b1; b++) {
+    const uint32_t cur = (b - b0) & 1;
+    PfRaw w[kVT][2];
+#pragma unroll
+    for (int v = 0; v < kVT; v++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) w[v][j] = nxt[v][j];
+    if (b + 1 < b1) x_dma(b + 1, cur ^ 1);
+    w_load(nxt, b + 1 < b1 ? b + 1 : b);   // the last iteration re-requests its own block (unconditional loads)
+    // 16 steps (pp, j, h) x kVT tiles = 16 kVT units, one scheduling region each: the unit's MT2 MFMAs, the dequantization of the
+    // next unit's A fragment and — in a step's first unit — the LDS reads of the next step's activation fragments
+    const uint8_t* xb = smem + cur * kPfSlabBytes + tk * 512;
+    const uint32_t swz = tk & 15;
+    h16x8 bf[2][MT2];
+    h16x2 S[kVT], O[kVT];
+    auto read_bf = [&](int st, h16x8* dst) {
+      const uint32_t q = (uint32_t)(8 * (st >> 2) + 2 * ((st >> 1) & 1) + (st & 1)) + 4 * g;
+#pragma unroll
+      for (int t = 0; t < MT2; t++) dst[t] = *reinterpret_cast<const h16x8*>(xb + t * 16384 + ((q ^ swz) << 4));
+    };
+    read_bf(0, bf[0]);
+    pf_scale<F>(w[0][0], 0, n, 2 * g, S[0], O[0]);
+    h16x8 af[2];
+    af[0] = pf_frag<F>(w[0][0], 0, 0, S[0], O[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16 * kVT; u++) {
+      const int st = u / kVT, v = u % kVT;
+      if (u + 1 < 16 * kVT) {
+        const int st2 = (u + 1) / kVT, v2 = (u + 1) % kVT, pp2 = st2 >> 2, j2 = (st2 >> 1) & 1, h2 = st2 & 1;
+        if (h2 == 0 && (F == PF_Q6K || j2 == 0)) pf_scale<F>(w[v2][j2], pp2, n, 2 * g + j2, S[v2], O[v2]);
+        af[(u + 1) & 1] = pf_frag<F>(w[v2][j2], pp2, h2, S[v2], O[v2]);
+      }
+#pragma unroll
+      for (int t = 0; t < MT2; t++) acc[v][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[u & 1], bf[st & 1][t], acc[v][t], 0, 0, 0);
+      if (v == 0 && st + 1 < 16) read_bf(st + 1, bf[(st + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    LGH_PF_STAMP(2 + 2 * (b - b0 < 5 ? b - b0 : 5));
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    __syncthreads();
+    LGH_PF_STAMP(3 + 2 * (b - b0 < 5 ? b - b0 : 5));
+  }
+  // partial sums: lane holds, per (32-row tile, 32-token tile), rows 8i + 4g .. + 3 (i = 0..3) of token l & 31
+  uint32_t row0 = 0;
+  if (G.row_base) asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(row0) : "s"(G.row_base) : "memory");
+  float* part = G.part + ((size_t)ks * G.part_rows + row0) * G.ncols;
+#pragma unroll
+  for (int v = 0; v < kVT; v++) {
+#pragma unroll
+    for (int t = 0; t < MT2; t++) {
+      const uint32_t tok = (uint32_t)t * 32 + tk;
+      if (tok >= m_tiles * 16) continue;   // (exactly the rows the 16-token form writes)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (tile0 + 2 * v + (i >> 1) >= sg.ntiles) continue;
+        const uint32_t col = sg.col0 + (tile0 + 2 * v) * 16 + 8 * i + 4 * g;
+        const f32x16 a = acc[v][t];
+        const f32x4 o = {a[4 * i], a[4 * i + 1], a[4 * i + 2], a[4 * i + 3]};
+        *reinterpret_cast<f32x4*>(part + (size_t)tok * G.ncols + col) = o * (1.0f / kPfScale);
+      }
+    }
+  }
+#ifdef LGH_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  LGH_PF_STAMP(14);
+}
+
 template <uint32_t MASK>
 __global__ void __launch_bounds__(kPfWaves * 64) pf_gemm_kernel(const PfGemm G) {
   extern __shared__ __attribute__((aligned(16))) uint8_t pf_smem[];
@@ -358,12 +494,21 @@ __global__ void __launch_bounds__(kPfWaves * 64) pf_gemm_kernel(const PfGemm G) 
     if (cnt == 0) return;
     m_tiles = (cnt + 15) / 16;
   }
+#if PF_SHAPE32 && PF_EXP == 0
+#define LGH_PF_RUN(F)                                                                    \
+  do {                                                                                   \
+    if (m_tiles <= 2) pf_body32<F, 1>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);          \
+    else if (m_tiles <= 4) pf_body32<F, 2>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);     \
+    else pf_body32<F, kPfMT / 2>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);               \
+  } while (0)
+#else
 #define LGH_PF_RUN(F)                                                                    \
   do {                                                                                   \
     if (m_tiles <= 2) pf_body<F, 2>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);            \
     else if (m_tiles <= 4) pf_body<F, 4>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);       \
     else pf_body<F, kPfMT>(G, sg, rg, blockIdx.y, m_tiles, pf_smem);                     \
   } while (0)
+#endif
   if (is(PF_Q4K)) LGH_PF_RUN(PF_Q4K);
   else if (is(PF_Q6K)) LGH_PF_RUN(PF_Q6K);
   else if (is(PF_Q5K)) LGH_PF_RUN(PF_Q5K);
