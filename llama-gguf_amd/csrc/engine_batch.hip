@@ -472,13 +472,13 @@ int lgh_batch_create(lgh_ctx* c, uint32_t max_batch) {
     HIP_TRYB(c, LGH_OPERATION_FAILED, hipMemsetAsync(Bs.vcache[i], 0, n, c->stream));
     c->stats.kv_bytes += 2 * n;
   }
-  {   // MoE layers with top-k <= 2: the expert-grouped step's buffers ((sequence, slot) pairs)
+  {   // MoE layers: the expert-grouped step's buffers ((sequence, slot) pairs)
     bool any_moe = false;
     for (uint32_t i = c->l0; i < c->l1; i++) any_moe = any_moe || c->layers[i].moe();
     // (the multi-sequence kernels run 8-wave workgroups: both expert shapes must plan to T x G = 8, as Mixtral's do)
     MvPlan pg{}, pd{};
     const bool plans = mvq_plan(H, EI, 2, &pg, EI) == hipSuccess && mvq_plan(EI, H, 1, &pd, H) == hipSuccess && pg.threads == 512 && pd.threads == 512;
-    if (any_moe && plans && d.num_experts_per_token <= 2 && d.num_experts <= 64 && EI % 256 == 0) {
+    if (any_moe && plans && d.num_experts_per_token <= 8 && d.num_experts <= 64 && EI % 256 == 0) {
       const size_t np = B * d.num_experts_per_token;
       uint8_t* xq_m = nullptr;
       float* ssq_m = nullptr;

@@ -18,6 +18,8 @@ def _engines(pkg, name, mix, max_seq=96, n_single=1, **kw):
         # expert width 1024 (4 blocks of 256 -> 8-wave plans, like Mixtral's 14336): the step reads every selected expert ONCE for
         # all sequences that chose it (engine_batch.hip); "test-moe" (768: 3 blocks) stays on the sequence-by-sequence MoE path
         name, kw = "test-moe", dict(kw, expert_intermediate_size=1024)
+    if name == "test-moe-e1024-k4":   # four of eight experts per token (the grouped step's entry lists hold up to 4 pairs per sequence)
+        name, kw = "test-moe", dict(kw, expert_intermediate_size=1024, num_experts=8, num_experts_per_token=4)
     if name == "mixtral-8x7b-3l":
         # Mixtral's own widths (8 experts of 14336, hidden 4096, vocabulary cut to 4096 for the test's run time), three layers — one
         # Q6_K and two Q5_K down projections under Q5_K_M: the expert-grouped step on the launch plans the full model runs with
@@ -43,6 +45,7 @@ def _history(cfg, seq, n):
                                         ("test-dense", "Q5_K_M", 12), ("test-dense", "Q8_0", 9), ("test-dense-d128", "Q6_K", 16),
                                         ("test-moe", "Q5_K_M", 3), ("test-moe", "Q4_K_M", 16),
                                         ("test-moe-e1024", "Q5_K_M", 3), ("test-moe-e1024", "Q4_K_M", 16), ("test-moe-e1024", "Q8_0", 7),
+                                        ("test-moe-e1024-k4", "Q5_K_M", 5), ("test-moe-e1024-k4", "Q4_K_M", 16),
                                         ("mixtral-8x7b-3l", "Q5_K_M", 6), ("mixtral-8x7b-3l", "Q5_K_M", 16)])
 def test_every_sequence_gets_the_single_sequence_logits_bitwise(pkg, name, mix, B):
     """B sequences with different histories and RAGGED lengths, token by token through lgh_forward_multi; each sequence's logits
