@@ -93,7 +93,7 @@ enum MvEpilogue : int {
   EPI_ROPE_K = 4,      // rotate, then write into K cache row *pos        (layers.rs:577-600)
   EPI_V_CACHE = 5,     // write into V cache row *pos
   EPI_MOE_SWIGLU = 6,  // out[row] = silu(v0)*v1 ; out2[row] = silu(v2)*v3 (two selected experts)
-  EPI_MOE_DOWN = 7,    // out[row] = (w0*v0 + w1*v1 ...) + resid[row]     (moe.rs:363-368)
+  EPI_MOE_DOWN = 7,    // out[row] = (out2[row] or 0) + w0*v0 + w1*v1 (+ resid[row])   (moe.rs:363-368, two experts per launch)
 };
 
 struct MvPass {

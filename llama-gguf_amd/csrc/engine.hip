@@ -477,8 +477,8 @@ int ffn_forward(lgh_ctx* c, LayerW& Lw, const FfnView& v, const float* next_nw, 
     return fail(c, LGH_UNSUPPORTED, "MoE needs fused-format experts and top-k <= 8");
   // The selected experts run two at a time (a launch carries up to four passes: gate and up of two experts).  Every group
   // reads the SAME normalised h, so the running sum lives in a scratch vector until the last group writes the residual
-  // stream: tmp = (w0 e0 + w1 e1) + h; tmp = (w2 e2 + w3 e3) + tmp; ...; h = (...) + tmp   (moe.rs:363-368 adds the weighted
-  // expert outputs in selection order and then the residual; same terms, grouped by two).
+  // stream: tmp = 0 + w0 e0 + w1 e1; tmp = tmp + w2 e2 + w3 e3; ...; h = (tmp + ...) + h — moe.rs:363-368's order exactly:
+  // one sum over the weighted expert outputs in selection order, then the residual.
   for (uint32_t g0 = 0; g0 < topk; g0 += 2) {
     const uint32_t ng = std::min(2u, topk - g0);
     const bool first_g = g0 == 0, last_g = g0 + ng >= topk;
@@ -505,7 +505,8 @@ int ffn_forward(lgh_ctx* c, LayerW& Lw, const FfnView& v, const float* next_nw, 
       }
       sp.epi = EPI_MOE_DOWN;
       sp.out = last_g ? v.hidden : v.xnorm;
-      sp.resid = first_g ? v.hidden : v.xnorm;
+      sp.out2 = first_g ? nullptr : v.xnorm;     // (EPI_MOE_DOWN: the running sum of the earlier groups)
+      sp.resid = last_g ? v.hidden : nullptr;
       sp.moe_w = v.moe_w + g0;
       sp.xq_next = last_g && next_mfma ? 2 : 0; sp.xq_next_nw = next_nw;
       if ((rc = launch_mv(c, LGH_K_DOWN, &sp, 1, nullptr, Lw.down_exps.k))) return rc;

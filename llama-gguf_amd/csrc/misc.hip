@@ -324,14 +324,9 @@ __global__ void __launch_bounds__(256) moe_combine_kernel(const float* __restric
                                                           float* __restrict__ ssq, uint32_t ssq_stride) {
   const uint32_t s = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
   if (row >= H) return;
-  // (the single-sequence engine runs the selected experts two at a time, engine.hip moe_forward: (w0 e0 + w1 e1) + h, then
-  // (w2 e2 + w3 e3) + that, ... — the same grouping here, so that top-k > 2 is bit-identical to it as well)
-  float outv = hidden[(size_t)s * H + row];
-  for (uint32_t g0 = 0; g0 < top_k; g0 += 2) {
-    float acc = 0.0f;
-    for (uint32_t p = g0; p < top_k && p < g0 + 2; p++) acc += moe_w[s * top_k + p] * tmp[((size_t)s * top_k + p) * H + row];
-    outv = acc + outv;
-  }
+  float acc = 0.0f;
+  for (uint32_t p = 0; p < top_k; p++) acc += moe_w[s * top_k + p] * tmp[((size_t)s * top_k + p) * H + row];
+  const float outv = acc + hidden[(size_t)s * H + row];
   hidden[(size_t)s * H + row] = outv;
   if (xq) xq_store_chunk(xq + (size_t)s * xq_stride, row >> 4, outv * (nw ? nw[row] : 1.0f), ssq ? ssq + (size_t)s * ssq_stride : nullptr, outv);
 }

@@ -17,7 +17,7 @@ struct MvEpiPre { float a, b; bool valid; };
 // `resid` come from the caller's first batch of scalar loads — fetched here they would be two more dependent round trips.
 __device__ __forceinline__ void mv_epilogue_prefetch_resid(int epi, const float* resid, const float* xq_nw, uint32_t n_rows, uint32_t wg,
                                                            uint32_t rows_per_wg, MvEpiPre& pre, uint32_t tid = threadIdx.x) {
-  if (epi == EPI_RESID || epi == EPI_MOE_DOWN) {
+  if (resid && (epi == EPI_RESID || epi == EPI_MOE_DOWN)) {
     const uint32_t t = tid, row = wg * rows_per_wg + t;
     if (t < rows_per_wg && row < n_rows) {
       pre.a = resid[row];
@@ -119,9 +119,12 @@ __device__ __forceinline__ void mv_epilogue_view(const MvLaunch& L, const MvSeg&
       break;
     }
     case EPI_MOE_DOWN: {
-      float acc = 0.0f;  // moe.rs:363-368: zero-initialised, += weight * expert_out in selection order
+      // moe.rs:363-368: ONE zero-initialised sum, += weight * expert_out over all selected experts in selection order, then the
+      // residual.  The experts run two per launch: a launch continues the running sum the earlier ones left (S.out2; none: it
+      // starts from zero) and only the last one adds the residual (resid; none: the output is the running sum).
+      float acc = S.out2 ? S.out2[row] : 0.0f;
       for (int p = 0; p < S.npass; p++) acc += S.moe_w[p] * rowval(p, t);
-      outv = acc + (pre.valid ? pre.a : V.resid[row]);
+      outv = V.resid ? acc + (pre.valid ? pre.a : V.resid[row]) : acc;
       V.out[row] = outv;
       has_out = true;
       break;
