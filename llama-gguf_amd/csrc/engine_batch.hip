@@ -6,8 +6,9 @@
 // SLOTS — a slot = one sequence's KV caches + position — and lgh_forward_multi feeds one token to each listed slot in ONE pass
 // over the weights: every quantized mat-vec launch reads its tiles once and multiplies them with all n_seq input vectors
 // (matvec_batch.hip), attention / its merge / embedding / arg-max run with the sequence as the grid's second dimension (over f32 or
-// TurboQuant slots); MoE layers route every sequence to its own experts: from 7 sequences on the step's (sequence, slot) pairs are
-// grouped by expert and each selected expert is read once, below that the FFN runs sequence by sequence.  Every sequence's logits are
+// TurboQuant slots); MoE layers route every sequence to its own experts: from 3 sequences on (moe_group_min) the step's (sequence,
+// slot) pairs are grouped by expert and each selected expert is read once — all experts of a layer in one gate | up and one down
+// launch, the expert as the grid's third dimension — below that the FFN runs sequence by sequence.  Every sequence's logits are
 // bit-identical to what the single-sequence engine computes for the same tokens (tests/test_gpu_batch.py): same kernels'
 // arithmetic, same summation orders.
 //
@@ -271,8 +272,8 @@ int enqueue_multi(lgh_ctx* c, uint32_t n_seq, bool greedy) {
       }
     } else if (Bs.moe_act && n_seq >= moe_group_min()) {
       // ---- MoE, every selected expert's matrices read ONCE for the step (MoeLayer::forward per sequence, moe.rs:321-413, regrouped):
-      // router per sequence -> the (sequence, slot) pairs grouped by expert -> per expert a gate|up launch over its pairs
-      // (SwiGLU, activation + XQ image per pair) and a down launch (output per pair) -> h += sum_p w_p * down_p in selection order
+      // router -> the (sequence, slot) pairs grouped by expert -> a gate|up launch, every expert over its pairs (SwiGLU, activation
+      // + XQ image per pair), and a down launch (output per pair) -> h += sum_p w_p * down_p in selection order
       const uint32_t topk = d.num_experts_per_token, ne = d.num_experts, EF = Lw.gate_exps.n;
       // (the router for all sequences in one launch: selections and weights packed [sequence][top_k])
       if ((rc = run_k(c, LGH_K_ROUTER, LGH_SYM_ROUTER, (uint64_t)ne * H * 4, [&] {
