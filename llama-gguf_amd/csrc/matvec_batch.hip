@@ -373,9 +373,14 @@ __global__ void __launch_bounds__(kBWaves * 64) mvqb2_kernel(const Mvqb2Geom Gm,
         load_a(pa0 + a_step, xa[1]);
         load_s(px0, xs2[0][0]);
         load_s(px0 + (uint32_t)kXqRecord, xs2[0][1]);
+#ifdef LGH_MVQB2_NOMATH   /* experiment: the weight stream, the unpacking and the record staging only (one sequence's arithmetic) */
+        const uint32_t n_seq_math = min(n_seq, 1u);
+#else
+        const uint32_t n_seq_math = n_seq;
+#endif
 #pragma unroll
         for (int g = 0; g < NB / 2; g++) {
-          if ((uint32_t)(2 * g) < n_seq) {
+          if ((uint32_t)(2 * g) < n_seq_math) {
             MacD m0, m1;
             mvq_mac_mfma(t, xa[0].a, m0);
             mvq_mac_mfma(t, xa[1].a, m1);
