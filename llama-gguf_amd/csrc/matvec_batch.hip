@@ -235,7 +235,10 @@ struct Mvqb2Geom {
   uint32_t nslots;            // partial sums per (sequence, row) in the buffer: 1 (SEQ) or T
 };
 
-constexpr uint32_t kXStageBytes = 40 * 1024;
+#ifndef LGH_XSTAGE_KB
+#define LGH_XSTAGE_KB 40   /* (experiment builds vary it: the cost of a chunk boundary, profiles/r03e_batched_decode.md) */
+#endif
+constexpr uint32_t kXStageBytes = LGH_XSTAGE_KB * 1024;
 // (the two-format instantiations at 16 sequences have no registers to spare: smaller chunks, fewer staging registers)
 __host__ __device__ constexpr uint32_t mvqb2_stage_bytes(bool single_format, int nb) { return !single_format && nb == 16 ? 24u * 1024u : kXStageBytes; }
 constexpr uint32_t kXZeroBytes = 2 * 1280 + 256;   // the zero block; also what an odd last sequence's partner may read past the records
